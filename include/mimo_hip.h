@@ -1,0 +1,196 @@
+/*
+ * mimo_hip.h — C-ABI of libmimo_hip.so: the MI355X (gfx950) kernels behind the MIMO
+ * denoising hot path (reference_unet + denoising_unet + sd-vae-ft-mse + pose guider).
+ *
+ * The reference (menyifang/MIMO) has NO native code and NO FFI on this path: every op
+ * is a stock torch/diffusers call made from Python.  The entry points
+ * below are therefore what a maintainer would bind (ctypes) *in
+ * place of* those stock ops; each one cites the reference call site it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types.  All pointers are DEVICE pointers that
+ *     the caller allocated (torch.empty(...).data_ptr()); the library never allocates,
+ *     frees or retains device memory and keeps no mutable global state.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - return 0 on success; negative MIMO_E* for a rejected argument; positive values
+ *     are hipError_t from the launch.
+ *   - activations are channels-last "token-major": an image batch [n, H, W, C] is the
+ *     row-major matrix [n*H*W, C].  `half16` tensors hold IEEE fp16 or bf16 according
+ *     to the `dtype` argument (MIMO_F16 / MIMO_BF16); MFMA accumulation is fp32.
+ */
+#ifndef MIMO_HIP_H
+#define MIMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMO_OK 0
+#define MIMO_EINVAL (-1)   /* bad shape / alignment / flag combination */
+#define MIMO_EDTYPE (-2)   /* unknown dtype code */
+#define MIMO_EARCH (-3)    /* no gfx950 device */
+
+#define MIMO_F16 0
+#define MIMO_BF16 1
+
+/* epilogue flags shared by mimo_gemm / mimo_conv2d */
+#define MIMO_EPI_SILU 1u      /* v = silu(v) after the bias terms, before the residual */
+#define MIMO_EPI_GEGLU 2u     /* weight rows interleaved [16 value | 16 gate]; out = value*gelu_erf(gate), N_out = N/2 */
+#define MIMO_EPI_OUT_F32 4u   /* store fp32 (else half16) */
+#define MIMO_EPI_RES_F32 8u   /* residual tensor is fp32 (else half16) */
+
+int mimo_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * mimo_gemm: out[M,N] = epi( A[M,K] . W[N,K]^T )
+ *   replaces every nn.Linear / 1x1 nn.Conv2d on the path:
+ *     attention to_q/to_k/to_v/to_out      (diffusers Attention; called src/models/attention.py:321-345,
+ *                                            src/models/mutual_self_attention.py:154-197)
+ *     GEGLU feed-forward                    (diffusers FeedForward; src/models/attention.py:429,
+ *                                            src/models/motion_module.py:258)
+ *     Transformer3DModel proj_in/proj_out   (src/models/transformer_3d.py:124-130,148-165)
+ *     motion-module proj_in/proj_out        (src/models/motion_module.py:158,172)
+ *     time embedding + time_emb_proj        (src/models/unet_3d_edit_bkfill.py:462-468, src/models/resnet.py:226)
+ *   A: half16 row-major, leading dimension lda (elements).  W: half16 [N,K] row-major
+ *   (torch Linear.weight layout).  K % 8 == 0, lda % 8 == 0, 16-byte aligned pointers.
+ *   epilogue: v = acc; +bias[n] (fp32, nullable); +img_bias[(m / rows_per_img), n]
+ *   (fp32 [M/rows_per_img, N], nullable); SILU; +residual[m, ldr] (nullable); *out_scale;
+ *   store to out[m, ldo].
+ * --------------------------------------------------------------------------------- */
+int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+              int64_t M, int N, int K, const float* bias, const float* img_bias,
+              int64_t rows_per_img, const void* residual, int64_t ldr, float out_scale,
+              unsigned flags, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * mimo_conv2d: channels-last implicit-GEMM convolution (3x3 or 1x1), MFMA.
+ *   replaces InflatedConv3d / nn.Conv2d + the fused adds around it:
+ *     ResnetBlock3D conv1 (+ time_emb_proj add), conv2 (+ shortcut add)   src/models/resnet.py:217-247
+ *     Downsample3D (stride 2), Upsample3D (nearest + conv)                src/models/resnet.py:53-120
+ *     conv_in (+ pose_cond_fea add), conv_out                             src/models/unet_3d_edit_bkfill.py:483-485,569-571
+ *     PoseGuider convs (+ SiLU)                                           src/models/pose_guider.py:47-57
+ *     diffusers ResnetBlock2D/Downsample2D/Upsample2D and the VAE Encoder/Decoder convs
+ *   in:  half16 [n, Hin, Win, Cin]; Cin % 8 == 0.
+ *   W:   half16 [Cout, ks*ks*Cin (+ Cin2)], K index = (ky*ks + kx)*Cin + ci, then the
+ *        optional extra 1x1 tap over in2.
+ *   in2: optional second source half16 [n, Hout, Wout, Cin2] contributing an extra
+ *        1x1 tap (the ResBlock conv_shortcut fused as additional K).
+ *   Spatial map: output (oy,ox) reads virtual input (oy*stride - pad_t + ky, ...);
+ *   the virtual input is `in` itself, or its nearest-neighbour upsampling to
+ *   [Hup, Wup] when Hup > 0 (src index = floor(dst * scale), scale = Hin/Hup as
+ *   float, exactly torch's 'nearest').  Zero padding outside.
+ *   epilogue: as mimo_gemm with rows_per_img = Hout*Wout.
+ * --------------------------------------------------------------------------------- */
+typedef struct mimo_conv_params {
+  int n, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int ksize;          /* 1 or 3 */
+  int stride;         /* 1 or 2 */
+  int pad_t, pad_l;   /* zero padding before the first row / column */
+  int Hup, Wup;       /* 0,0 = no upsampling; else virtual input size */
+  int Cin2;           /* channels of in2 (0 = none) */
+} mimo_conv_params;
+
+int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
+                const mimo_conv_params* p, const float* bias, const float* img_bias,
+                const void* residual, float out_scale, unsigned flags, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * GroupNorm (per image, 32 groups typical) over a *virtual channel concat* of two
+ * sources (torch.cat([h, skip], dim=1) is never materialised, src/models/unet_3d_blocks.py:697,827).
+ *   replaces InflatedGroupNorm / nn.GroupNorm (+ F.silu)  src/models/resnet.py:20-28,220-221,231,237;
+ *   src/models/transformer_3d.py:124; src/models/motion_module.py:154; VAE norms.
+ *   x1: [n, HW, C1], x2: [n, HW, C2] (nullable, C2 = 0); each fp32 or half16 (x_is_f32).
+ *   stats: fp32 [n, groups, 2] = (mean, rstd).  apply: y = (x-mean)*rstd*gamma+beta,
+ *   optional SiLU, stored half16 [n, HW, C1+C2].  raw_out (nullable): plain half16 cast
+ *   of the concatenated input (feeds the fused 1x1 shortcut / upsample conv).
+ * --------------------------------------------------------------------------------- */
+int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
+                          int n, int64_t HW, int groups, float eps, float* stats, void* stream);
+int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
+                          int n, int64_t HW, int groups, const float* stats, const float* gamma,
+                          const float* beta, int silu, void* out, void* raw_out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * LayerNorm over the last dim of x [rows, C] (fp32 or half16) -> half16, optional
+ * additive positional table pe[(row / rows_per_frame) % pe_frames, C] (fp32).
+ *   replaces nn.LayerNorm (src/models/attention.py:329-360; src/models/motion_module.py:230-258)
+ *   and PositionalEncoding.forward (src/models/motion_module.py:276-279).
+ * --------------------------------------------------------------------------------- */
+int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C, float eps,
+                    const float* gamma, const float* beta, const float* pe, int64_t rows_per_frame,
+                    int pe_frames, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional
+ * second key/value segment shared by all batch rows b >= seg2_first_batch
+ * (the reference-attention bank):
+ *   replaces diffusers Attention/AttnProcessor2_0 SDPA as called in read mode
+ *   (src/models/mutual_self_attention.py:154-197: cond rows attend [self || bank], uncond
+ *   rows attend self) and in write mode / plain self-attention (:137-147).
+ *   q,k,v: half16 token-major [B, Nq|Nk, ld*] with head h at columns [h*d, (h+1)*d);
+ *   k2,v2: half16 [Nk2, ld*2] (nullable).  out: half16 [B, Nq, ldo].  d % 8 == 0, d <= 160.
+ * --------------------------------------------------------------------------------- */
+int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                   int64_t ldv, const void* k2, int64_t ldk2, const void* v2, int64_t ldv2, void* out,
+                   int64_t ldo, int B, int Nq, int Nk, int Nk2, int seg2_first_batch, int heads, int d,
+                   float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Temporal attention over the frame axis without materialising '(b f) d c -> (b d) f c'
+ *   replaces VersatileAttention.forward (src/models/motion_module.py:353-390).
+ *   q,k,v: half16 [b*F, HW, ld*] (frame-major tokens); attention is over the F frames
+ *   of each (batch b, pixel p, head h).  F <= 32.  out: half16 [b*F, HW, ldo].
+ * --------------------------------------------------------------------------------- */
+int mimo_temporal_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                            const void* v, int64_t ldv, void* out, int64_t ldo, int b, int F,
+                            int64_t HW, int heads, int d, float scale, void* stream);
+
+/* row softmax: in fp32 [rows, cols] * scale -> half16 [rows, ldo] (VAE mid-block attention,
+ * 1 head d=512: scores via mimo_gemm, softmax here, P.V via mimo_gemm). */
+int mimo_softmax_rows(int dtype, const float* in, int64_t ldi, void* out, int64_t ldo, int64_t rows,
+                      int cols, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * layout / elementwise helpers at the boundary
+ * --------------------------------------------------------------------------------- */
+/* [b, C, F, H, W] (fp32 or half16 per in_is_f32) frame-gathered -> half16 [b*F', H*W, Cpad] with
+ * channels >= C zero; frame_idx (int32 [F'] device, nullable = identity).  Replaces the
+ * `rearrange "b c f h w -> (b f) c h w"` churn (src/models/resnet.py:13-15) at the model input. */
+int mimo_ncfhw_to_tokens(const void* in, int in_is_f32, int dtype, int b, int C, int F, int H, int W,
+                         const int* frame_idx, int Fsel, int Cpad, int64_t out_ld, int out_col0,
+                         void* out, void* stream);
+/* tokens (fp32 or half16) [b*F, H*W, ld] cols [0,C) -> fp32 [b, C, F, H, W] */
+int mimo_tokens_to_ncfhw(const void* in, int in_is_f32, int dtype, int64_t ld, int b, int C, int F,
+                         int H, int W, float scale, float* out, void* stream);
+/* half16/fp32 cast with optional second output */
+int mimo_cast(const void* in, int in_is_f32, int dtype, int64_t count, void* out_half, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Window accumulate + classifier-free guidance + DDIM (v-prediction, eta = 0) step
+ *   replaces src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py:540-553
+ *   (noise_pred/counter, chunk(2), guidance, scheduler.step) in one pass.
+ *   acc: fp32 [2, 4, F, h, w] summed window predictions (row 0 uncond, row 1 cond; if
+ *   !cfg: [1,...]).  counter: fp32 [F].  latents: fp32 [1,4,F,h,w], updated in place.
+ * --------------------------------------------------------------------------------- */
+int mimo_cfg_ddim_step(const float* acc, const float* counter, float* latents, int C, int F,
+                       int64_t HW, int cfg, float guidance, float sqrt_a_t, float sqrt_1ma_t,
+                       float sqrt_a_prev, float sqrt_1ma_prev, void* stream);
+/* acc[:, :, frames[j]] += pred[:, :, j]; counter[frames[j]] += 1, with pred given as the UNet's
+ * token-major output fp32 [bb*Fw, HW, ld] (channels [0,C)); frames: int32 [Fw] device. */
+int mimo_window_accumulate(const float* pred, int64_t ld, const int* frames, int Fw, int bb, int C,
+                           int F, int64_t HW, float* acc, float* counter, void* stream);
+
+/* VAE image post-process: tokens half16/fp32 [n, H*W, ld] (3 ch) -> fp32 [n,3,H,W] = clamp(x/2+0.5,0,1)
+ *   (src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py:123) */
+int mimo_tokens_to_image(const void* in, int in_is_f32, int dtype, int64_t ld, int n, int H, int W,
+                         float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMO_HIP_H */

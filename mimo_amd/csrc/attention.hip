@@ -1,0 +1,418 @@
+// attention.hip — attention cores of the denoising path (gfx950, MFMA 32x32x16).
+//
+//  * attn_kernel: spatial multi-head flash attention with an optional second key/value
+//    segment (the reference-attention bank) shared by all batch rows >= seg2_first_batch.
+//    Replaces diffusers Attention/SDPA as driven by src/models/mutual_self_attention.py:154-197
+//    (read mode: cond rows attend [self || bank], uncond rows attend self only — computed in
+//    ONE launch, no overwrite pass) and :137-147 (write mode / plain self-attention).
+//  * temporal_attn_kernel: attention over the <=32 frames of each (pixel, head), reading the
+//    frame-major token layout in place (no '(b f) d c -> (b d) f c' copies).
+//    Replaces VersatileAttention.forward, src/models/motion_module.py:353-390.
+//  * softmax_rows_kernel: plain row softmax for the single-head d=512 VAE attention.
+//
+// Formulation ("swapped"): S^T = K.Q^T and O^T = V^T.P^T, so a lane owns ONE query column
+// (q = lane & 31): the online-softmax max/sum are in-lane reductions plus one xor-32
+// shuffle, the O rescale needs no broadcast, and P feeds the second MFMA straight from the
+// accumulator registers (the k-index permutation is applied identically to V^T's fragment).
+#include "common.cuh"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+  const uint16_t *q, *k, *v, *k2, *v2;
+  uint16_t* out;
+  int64_t ldq, ldk, ldv, ldk2, ldv2, ldo;
+  int B, Nq, Nk, Nk2, seg2_first_batch, heads;
+  float scale_log2;
+};
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
+  constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
+  constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
+  constexpr int KP = KS * 16 + 8;          // K tile pitch (halfs): odd multiple of 16 bytes
+  constexpr int VP = KV_TILE + 4;          // V^T tile pitch (halfs): 8 * odd bytes
+  constexpr int DC = D / 8;                // 16-byte chunks per head row
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KV_TILE * KP];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[OT * 32 * VP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, li = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  // zero the LDS once: pad columns / rows are never written again
+  for (int i = tid; i < KV_TILE * KP / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
+  for (int i = tid; i < OT * 32 * VP / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+
+  // Q^T fragments (B operand): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8]
+  uint4 qf[KS];
+  {
+    const int qr = q0 + li;
+    const uint16_t* qp = a.q + ((int64_t)b * a.Nq + qr) * a.ldq + head * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int kk = 16 * s + 8 * h2;
+      qf[s] = (qr < a.Nq && kk < D) ? *reinterpret_cast<const uint4*>(qp + kk) : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  f32x16 ot[OT];
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nseg = (a.k2 && a.Nk2 > 0 && b >= a.seg2_first_batch) ? 2 : 1;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const uint16_t* kb = seg == 0 ? a.k + (int64_t)b * a.Nk * a.ldk : a.k2;
+    const uint16_t* vb = seg == 0 ? a.v + (int64_t)b * a.Nk * a.ldv : a.v2;
+    const int64_t ldk = seg == 0 ? a.ldk : a.ldk2;
+    const int64_t ldv = seg == 0 ? a.ldv : a.ldv2;
+    const int nk = seg == 0 ? a.Nk : a.Nk2;
+
+    for (int kv0 = 0; kv0 < nk; kv0 += KV_TILE) {
+      __syncthreads();  // previous tile fully consumed (also orders the initial zero-fill)
+      // ---- stage K tile [64][D] row-major ----
+      for (int id = tid; id < KV_TILE * DC; id += 256) {
+        const int row = id / DC, cc = id - row * DC;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (kv0 + row < nk) val = *reinterpret_cast<const uint4*>(kb + (int64_t)(kv0 + row) * ldk + head * D + cc * 8);
+        *reinterpret_cast<uint4*>(&Ks[row * KP + cc * 8]) = val;
+      }
+      // ---- stage V tile transposed: Vt[d][kv] ----
+      for (int id = tid; id < KV_TILE * DC; id += 256) {
+        const int row = id & (KV_TILE - 1), cc = id >> 6;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (kv0 + row < nk) val = *reinterpret_cast<const uint4*>(vb + (int64_t)(kv0 + row) * ldv + head * D + cc * 8);
+        const uint32_t w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Vt[(cc * 8 + 2 * i) * VP + row] = (uint16_t)(w[i] & 0xffffu);
+          Vt[(cc * 8 + 2 * i + 1) * VP + row] = (uint16_t)(w[i] >> 16);
+        }
+      }
+      __syncthreads();
+
+      // ---- S^T = K.Q^T : two 32-kv sub-tiles ----
+      f32x16 st[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * t + li) * KP + 16 * s + 8 * h2]);
+          st[t] = HT<DT>::mfma32(kf, qf[s], st[t]);
+        }
+      }
+      // ---- online softmax over kv for this lane's query ----
+      float mt = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          const float sv = (kv < nk) ? st[t][r] * a.scale_log2 : -INFINITY;
+          st[t][r] = sv;
+          mt = fmaxf(mt, sv);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = exp2f(st[t][r] - m_use);
+          st[t][r] = p;
+          ps += p;
+        }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+
+      // ---- P^T fragments (B operand) straight from the accumulators ----
+      uint4 pf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = u >> 1, hh = u & 1;
+        pf[u].x = pack2<DT>(st[t][8 * hh + 0], st[t][8 * hh + 1]);
+        pf[u].y = pack2<DT>(st[t][8 * hh + 2], st[t][8 * hh + 3]);
+        pf[u].z = pack2<DT>(st[t][8 * hh + 4], st[t][8 * hh + 5]);
+        pf[u].w = pack2<DT>(st[t][8 * hh + 6], st[t][8 * hh + 7]);
+      }
+      // ---- O^T += V^T.P^T ----
+#pragma unroll
+      for (int dt = 0; dt < OT; ++dt) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint16_t* vr = &Vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
+          ot[dt] = HT<DT>::mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], ot[dt]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane (h2, q) holds O^T[d = 32 dt + (r&3) + 8 (r>>2) + 4 h2][q] ----
+  const int qr = q0 + li;
+  if (qr < a.Nq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    uint16_t* op = a.out + ((int64_t)b * a.Nq + qr) * a.ldo + head * D;
+#pragma unroll
+    for (int dt = 0; dt < OT; ++dt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = 32 * dt + 8 * c + 4 * h2;
+        if (d < D) {
+          uint2 o;
+          o.x = pack2<DT>(ot[dt][4 * c + 0] * inv, ot[dt][4 * c + 1] * inv);
+          o.y = pack2<DT>(ot[dt][4 * c + 2] * inv, ot[dt][4 * c + 3] * inv);
+          *reinterpret_cast<uint2*>(op + d) = o;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Temporal attention: one wave per (batch b, pixel p, head h); sequence = F <= 32 frames.
+// ------------------------------------------------------------------------------------
+struct TAttnArgs {
+  const uint16_t *q, *k, *v;
+  uint16_t* out;
+  int64_t ldq, ldk, ldv, ldo, HW;
+  int b, F, heads;
+  float scale_log2;
+};
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs a) {
+  constexpr int KS = (D + 15) / 16;
+  constexpr int OT = (D + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h2 = lane >> 5, li = lane & 31;
+  // unit id -> (b, pixel, head); heads fastest so the 4 waves of a block share token rows
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nunits = (int64_t)a.b * a.HW * a.heads;
+  if (unit >= nunits) return;
+  const int head = (int)(unit % a.heads);
+  const int64_t bp = unit / a.heads;
+  const int64_t pix = bp % a.HW;
+  const int bi = (int)(bp / a.HW);
+  const int F = a.F;
+  // token row of frame f: (bi*F + f)*HW + pix
+  const int64_t row0 = (int64_t)bi * F * a.HW + pix;
+
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+  {
+    const bool fok = li < F;
+    const int64_t row = row0 + (int64_t)li * a.HW;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int kk = 16 * s + 8 * h2;
+      uint4 kf = make_uint4(0, 0, 0, 0), qf = make_uint4(0, 0, 0, 0);
+      if (fok && kk < D) {
+        kf = *reinterpret_cast<const uint4*>(a.k + row * a.ldk + head * D + kk);
+        qf = *reinterpret_cast<const uint4*>(a.q + row * a.ldq + head * D + kk);
+      }
+      st = HT<DT>::mfma32(kf, qf, st);
+    }
+  }
+  float mt = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kv = (r & 3) + 8 * (r >> 2) + 4 * h2;
+    const float sv = kv < F ? st[r] * a.scale_log2 : -INFINITY;
+    st[r] = sv;
+    mt = fmaxf(mt, sv);
+  }
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float p = exp2f(st[r] - mt);
+    st[r] = p;
+    ps += p;
+  }
+  ps += __shfl_xor(ps, 32, 64);
+  const float inv = 1.f / ps;
+  uint4 pf[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    pf[u].x = pack2<DT>(st[8 * u + 0], st[8 * u + 1]);
+    pf[u].y = pack2<DT>(st[8 * u + 2], st[8 * u + 3]);
+    pf[u].z = pack2<DT>(st[8 * u + 4], st[8 * u + 5]);
+    pf[u].w = pack2<DT>(st[8 * u + 6], st[8 * u + 7]);
+  }
+#pragma unroll
+  for (int dt = 0; dt < OT; ++dt) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const int d = 32 * dt + li;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint16_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f = 16 * u + 4 * h2 + (j & 3) + 8 * (j >> 2);
+        e[j] = (d < D && f < F) ? a.v[(row0 + (int64_t)f * a.HW) * a.ldv + head * D + d] : (uint16_t)0;
+      }
+      uint4 vf;
+      vf.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+      vf.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+      vf.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+      vf.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+      o = HT<DT>::mfma32(vf, pf[u], o);
+    }
+    // lane (h2, q = li): o[r] = O^T[d = 32 dt + (r&3) + 8 (r>>2) + 4 h2][q]
+    if (li < F) {
+      uint16_t* op = a.out + (row0 + (int64_t)li * a.HW) * a.ldo + head * D;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = 32 * dt + 8 * c + 4 * h2;
+        if (dd < D) {
+          uint2 w;
+          w.x = pack2<DT>(o[4 * c + 0] * inv, o[4 * c + 1] * inv);
+          w.y = pack2<DT>(o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+          *reinterpret_cast<uint2*>(op + dd) = w;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Row softmax (fp32 in, half out): one block per row.
+// ------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int64_t ldi, uint16_t* out,
+                                                           int64_t ldo, int cols, float scale_log2) {
+  const int64_t row = blockIdx.x;
+  const float* x = in + row * ldi;
+  __shared__ float red[8];
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, x[c] * scale_log2);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += exp2f(x[c] * scale_log2 - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = threadIdx.x; c < cols; c += 256)
+    out[row * ldo + c] = HT<DT>::from_f(exp2f(x[c] * scale_log2 - m) * inv);
+}
+
+}  // namespace
+
+extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                              const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
+                              int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
+                              int seg2_first_batch, int heads, int d, float scale, void* stream) {
+  if (!q || !k || !v || !out || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return MIMO_EINVAL;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return MIMO_EINVAL;
+  if (Nk2 > 0 && (!k2 || !v2 || (ldk2 & 7) || (ldv2 & 7))) return MIMO_EINVAL;
+  if (heads > 65535 || B > 65535) return MIMO_EINVAL;
+  AttnArgs a;
+  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
+  a.k2 = Nk2 > 0 ? (const uint16_t*)k2 : nullptr; a.v2 = Nk2 > 0 ? (const uint16_t*)v2 : nullptr;
+  a.out = (uint16_t*)out;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldk2 = ldk2; a.ldv2 = ldv2; a.ldo = ldo;
+  a.B = B; a.Nq = Nq; a.Nk = Nk; a.Nk2 = Nk2; a.seg2_first_batch = seg2_first_batch; a.heads = heads;
+  a.scale_log2 = scale * LOG2E;
+  const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+#define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD>), grid, dim3(256), 0, st, a)
+  if (dtype == MIMO_F16) {
+    switch (d) {
+      case 40: ATTN_LAUNCH(MIMO_F16, 40); break;
+      case 64: ATTN_LAUNCH(MIMO_F16, 64); break;
+      case 80: ATTN_LAUNCH(MIMO_F16, 80); break;
+      case 160: ATTN_LAUNCH(MIMO_F16, 160); break;
+      default: return MIMO_EINVAL;
+    }
+  } else if (dtype == MIMO_BF16) {
+    switch (d) {
+      case 40: ATTN_LAUNCH(MIMO_BF16, 40); break;
+      case 64: ATTN_LAUNCH(MIMO_BF16, 64); break;
+      case 80: ATTN_LAUNCH(MIMO_BF16, 80); break;
+      case 160: ATTN_LAUNCH(MIMO_BF16, 160); break;
+      default: return MIMO_EINVAL;
+    }
+  } else {
+    return MIMO_EDTYPE;
+  }
+#undef ATTN_LAUNCH
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_temporal_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                       const void* v, int64_t ldv, void* out, int64_t ldo, int b, int F,
+                                       int64_t HW, int heads, int d, float scale, void* stream) {
+  if (!q || !k || !v || !out || b <= 0 || F <= 0 || F > 32 || HW <= 0 || heads <= 0) return MIMO_EINVAL;
+  if ((ldq & 7) || (ldk & 7) || (ldo & 3)) return MIMO_EINVAL;
+  TAttnArgs a;
+  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v; a.out = (uint16_t*)out;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.HW = HW; a.b = b; a.F = F; a.heads = heads;
+  a.scale_log2 = scale * LOG2E;
+  const int64_t units = (int64_t)b * HW * heads;
+  const int64_t nb = (units + 3) / 4;
+  if (nb > 0x7fffffff) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+#define TATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((temporal_attn_kernel<DT, DD>), dim3((unsigned)nb), dim3(256), 0, st, a)
+  if (dtype == MIMO_F16) {
+    switch (d) {
+      case 40: TATTN_LAUNCH(MIMO_F16, 40); break;
+      case 64: TATTN_LAUNCH(MIMO_F16, 64); break;
+      case 80: TATTN_LAUNCH(MIMO_F16, 80); break;
+      case 160: TATTN_LAUNCH(MIMO_F16, 160); break;
+      default: return MIMO_EINVAL;
+    }
+  } else if (dtype == MIMO_BF16) {
+    switch (d) {
+      case 40: TATTN_LAUNCH(MIMO_BF16, 40); break;
+      case 64: TATTN_LAUNCH(MIMO_BF16, 64); break;
+      case 80: TATTN_LAUNCH(MIMO_BF16, 80); break;
+      case 160: TATTN_LAUNCH(MIMO_BF16, 160); break;
+      default: return MIMO_EINVAL;
+    }
+  } else {
+    return MIMO_EDTYPE;
+  }
+#undef TATTN_LAUNCH
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_softmax_rows(int dtype, const float* in, int64_t ldi, void* out, int64_t ldo,
+                                 int64_t rows, int cols, float scale, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || rows > 0x7fffffff) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIMO_F16)
+    hipLaunchKernelGGL(softmax_rows_kernel<MIMO_F16>, dim3((unsigned)rows), dim3(256), 0, st, in, ldi, (uint16_t*)out, ldo, cols, scale * LOG2E);
+  else if (dtype == MIMO_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<MIMO_BF16>, dim3((unsigned)rows), dim3(256), 0, st, in, ldi, (uint16_t*)out, ldo, cols, scale * LOG2E);
+  else
+    return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}

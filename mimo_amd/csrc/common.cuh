@@ -1,0 +1,112 @@
+// common.cuh — shared device helpers for the gfx950 kernels of libmimo_hip.so.
+// CDNA4 only: wave = 64 lanes, MFMA 16x16x32 / 32x32x16 (f16|bf16 in, f32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mimo_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 16-bit storage is carried as raw uint16_t / uint4 (8 halfs); HT<DT> gives it meaning.
+template <int DT>
+struct HT;
+
+template <>
+struct HT<MIMO_F16> {
+  static __device__ __forceinline__ float to_f(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <>
+struct HT<MIMO_BF16> {
+  static __device__ __forceinline__ float to_f(uint16_t b) {
+    return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+  }
+  static __device__ __forceinline__ uint16_t from_f(float f) {
+    // round-to-nearest-even, NaN preserved
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)HT<DT>::from_f(lo) | ((uint32_t)HT<DT>::from_f(hi) << 16);
+}
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = HT<DT>::to_f((uint16_t)(w[i] & 0xffffu));
+    f[2 * i + 1] = HT<DT>::to_f((uint16_t)(w[i] >> 16));
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = pack2<DT>(f[0], f[1]);
+  v.y = pack2<DT>(f[2], f[3]);
+  v.z = pack2<DT>(f[4], f[5]);
+  v.w = pack2<DT>(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch F.gelu default
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b, b+8, b+16 ... (which the dispatcher
+// places on the same XCD) get consecutive logical ids, so tiles that share an operand panel
+// share one L2 (cdna_hip_programming.md T1, bijective form).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, slot = bid >> 3;
+  const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+#define MIMO_LAUNCH_CHECK()                    \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)

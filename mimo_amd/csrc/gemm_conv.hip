@@ -1,0 +1,334 @@
+// gemm_conv.hip — the MFMA workhorse of the denoising path: one LDS-tiled kernel that is
+// either a dense GEMM  out[M,N] = A[M,K].W[N,K]^T  or a channels-last implicit-GEMM
+// convolution (3x3 / 1x1, stride 1|2, optional nearest-upsample gather, optional extra 1x1
+// tap over a second tensor = fused ResBlock shortcut), with a fused epilogue
+// (bias, per-image bias = time embedding / collapsed cross-attention, SiLU, GEGLU,
+// residual add, fp32|half store).
+//
+// Reference ops replaced: see include/mimo_hip.h (mimo_gemm / mimo_conv2d).
+//
+// Tiling (gfx950): block = 256 threads = 4 waves (2 x 2); block tile 128 x (32*NR) x 64;
+// each wave owns 64 x (16*NR) as 4 x NR MFMA 16x16x32 tiles, fp32 accumulators in
+// registers.  Operands are staged global -> VGPR -> LDS (16-byte chunks, XOR-swizzled so
+// the ds_read_b128 fragment reads are bank-conflict-free), double-buffered with one
+// barrier per K-tile; the next tile's global loads are in flight under the MFMAs.
+// The MFMA is issued "swapped" (W fragment as the A operand) so that every lane ends up
+// with 4 consecutive output columns of one row -> 16-byte epilogue loads/stores.
+#include "common.cuh"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+struct GemmArgs {
+  const uint16_t* A;
+  const uint16_t* A2;
+  const uint16_t* W;
+  void* out;
+  const float* bias;
+  const float* img_bias;
+  const void* res;
+  int64_t lda, ldw, ldo, ldr, M, rows_per_img;
+  int N, K;
+  float out_scale;
+  unsigned flags;
+  int tiles_n;
+  // conv geometry
+  int Hin, Win, Cin, Hout, Wout, ks, stride, pad_t, pad_l, Hup, Wup, Cin2;
+  float sh, sw;
+  int chunks1, chunks2, nkt;
+};
+
+template <int DT, int NR, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+  constexpr int BN = 32 * NR;
+  constexpr int NRB = BN / 32;  // B rows staged per thread
+  __shared__ __attribute__((aligned(16))) uint4 As[2][BM * 8];
+  __shared__ __attribute__((aligned(16))) uint4 Bs[2][BN * 8];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lg = lane >> 4, li = lane & 15;
+
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = (int)(L / (unsigned)g.tiles_n);
+  const int tile_n = (int)(L % (unsigned)g.tiles_n);
+  const int64_t M0 = (int64_t)tile_m * BM;
+  const int N0 = tile_n * BN;
+
+  // ---- staging roles: thread -> (row srow + 32 j, 16-byte chunk sc) ----
+  const int srow = tid >> 3;
+  const int sc = tid & 7;
+  const int swz = sc ^ (srow & 7);  // (srow + 32 j) & 7 == srow & 7
+
+  // per-row A metadata
+  int64_t a_base[4];  // dense: row offset; conv: image index
+  int a_iy0[4], a_ix0[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t m = M0 + srow + 32 * j;
+    a_ok[j] = m < g.M;
+    if (CONV) {
+      const int64_t hw = (int64_t)g.Hout * g.Wout;
+      const int64_t img = a_ok[j] ? m / hw : 0;
+      const int rem = a_ok[j] ? (int)(m - img * hw) : 0;
+      const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
+      a_base[j] = img;
+      a_iy0[j] = oy * g.stride - g.pad_t;
+      a_ix0[j] = ox * g.stride - g.pad_l;
+    } else {
+      a_base[j] = m * g.lda;
+      a_iy0[j] = a_ix0[j] = 0;
+    }
+  }
+  bool b_ok[NRB];
+  int64_t b_base[NRB];
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const int n = N0 + srow + 32 * j;
+    b_ok[j] = n < g.N;
+    b_base[j] = (int64_t)n * g.ldw;
+  }
+
+  uint4 ra[4], rb[NRB];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tile = [&](int kt) {
+    if (CONV) {
+      const int ntap_tiles = g.ks * g.ks * g.chunks1;
+      if (kt < ntap_tiles) {
+        const int tap = kt / g.chunks1;
+        const int c = (kt - tap * g.chunks1) * BK + sc * 8;
+        const int ky = tap / g.ks, kx = tap - ky * g.ks;
+        const bool cok = c < g.Cin;
+        const int Hv = g.Hup > 0 ? g.Hup : g.Hin;
+        const int Wv = g.Hup > 0 ? g.Wup : g.Win;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int vy = a_iy0[j] + ky, vx = a_ix0[j] + kx;
+          const bool ok = a_ok[j] && cok && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+          int sy = vy, sx = vx;
+          if (g.Hup > 0) {
+            sy = min((int)floorf((float)vy * g.sh), g.Hin - 1);
+            sx = min((int)floorf((float)vx * g.sw), g.Win - 1);
+          }
+          const int64_t off = ((a_base[j] * g.Hin + sy) * g.Win + sx) * g.Cin + c;
+          ra[j] = ok ? *reinterpret_cast<const uint4*>(g.A + off) : zero4;
+        }
+        const int64_t kw = (int64_t)tap * g.Cin + c;
+#pragma unroll
+        for (int j = 0; j < NRB; ++j)
+          rb[j] = (b_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + kw) : zero4;
+      } else {
+        const int c = (kt - ntap_tiles) * BK + sc * 8;
+        const bool cok = c < g.Cin2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t m = M0 + srow + 32 * j;
+          ra[j] = (a_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.A2 + m * g.Cin2 + c) : zero4;
+        }
+        const int64_t kw = (int64_t)g.ks * g.ks * g.Cin + c;
+#pragma unroll
+        for (int j = 0; j < NRB; ++j)
+          rb[j] = (b_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + kw) : zero4;
+      }
+    } else {
+      const int k = kt * BK + sc * 8;
+      const bool kok = k < g.K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ra[j] = (a_ok[j] && kok) ? *reinterpret_cast<const uint4*>(g.A + a_base[j] + k) : zero4;
+#pragma unroll
+      for (int j = 0; j < NRB; ++j)
+        rb[j] = (b_ok[j] && kok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + k) : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) As[buf][(srow + 32 * j) * 8 + swz] = ra[j];
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) Bs[buf][(srow + 32 * j) * 8 + swz] = rb[j];
+  };
+
+  f32x4 acc[NR][4];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = g.nkt;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ch = (4 * s + lg) ^ (li & 7);
+      uint4 fa[4], fb[NR];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = As[buf][(wm * 64 + mi * 16 + li) * 8 + ch];
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) fb[ni] = Bs[buf][(wn * 16 * NR + ni * 16 + li) * 8 + ch];
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
+          acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds out[m = .. + li][n = .. + 4*lg + r], r = 0..3 ----
+  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
+  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
+  const bool do_silu = g.flags & MIMO_EPI_SILU;
+  const bool geglu = g.flags & MIMO_EPI_GEGLU;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t m = M0 + wm * 64 + mi * 16 + li;
+    if (m >= g.M) continue;
+    const int64_t img = g.img_bias ? m / g.rows_per_img : 0;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      if (geglu && (ni & 1)) continue;
+      const int n = N0 + wn * 16 * NR + ni * 16 + 4 * lg;
+      if (n >= g.N) continue;
+      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+      if (g.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (g.img_bias) {
+        const float4 b = *reinterpret_cast<const float4*>(g.img_bias + img * g.N + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      int no = n;
+      if (geglu) {
+        // gate tile = the next 16 packed columns; identical lane mapping
+        const int ni1 = (ni + 1 < NR) ? ni + 1 : ni;
+        float gt[4] = {acc[ni1][mi][0], acc[ni1][mi][1], acc[ni1][mi][2], acc[ni1][mi][3]};
+        if (g.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(g.bias + n + 16);
+          gt[0] += b.x; gt[1] += b.y; gt[2] += b.z; gt[3] += b.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(gt[r]);
+        no = (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg;
+      }
+      if (do_silu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (g.res) {
+        if (res_f32) {
+          const float4 r4 = *reinterpret_cast<const float4*>((const float*)g.res + m * g.ldr + no);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        } else {
+          const uint2 r2 = *reinterpret_cast<const uint2*>((const uint16_t*)g.res + m * g.ldr + no);
+          v[0] += HT<DT>::to_f((uint16_t)(r2.x & 0xffffu));
+          v[1] += HT<DT>::to_f((uint16_t)(r2.x >> 16));
+          v[2] += HT<DT>::to_f((uint16_t)(r2.y & 0xffffu));
+          v[3] += HT<DT>::to_f((uint16_t)(r2.y >> 16));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
+      if (out_f32) {
+        *reinterpret_cast<float4*>((float*)g.out + m * g.ldo + no) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o;
+        o.x = pack2<DT>(v[0], v[1]);
+        o.y = pack2<DT>(v[2], v[3]);
+        *reinterpret_cast<uint2*>((uint16_t*)g.out + m * g.ldo + no) = o;
+      }
+    }
+  }
+}
+
+template <int DT, bool CONV>
+int launch(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  const bool geglu = g.flags & MIMO_EPI_GEGLU;
+  // NR = 5 (BN = 160) divides every SD1.5 width (320/640/960/1280/1920/2560); NR = 4 otherwise
+  const bool use5 = !geglu && (g.N % 160 == 0);
+  const int BN = use5 ? 160 : 128;
+  const int64_t tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int64_t nwg = tiles_m * g.tiles_n;
+  if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+  if (use5)
+    hipLaunchKernelGGL((gemm_kernel<DT, 5, CONV>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<DT, 4, CONV>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+                         int64_t M, int N, int K, const float* bias, const float* img_bias,
+                         int64_t rows_per_img, const void* residual, int64_t ldr, float out_scale,
+                         unsigned flags, void* stream) {
+  if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return MIMO_EINVAL;
+  if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out))
+    return MIMO_EINVAL;
+  if ((flags & MIMO_EPI_GEGLU) && (N & 31)) return MIMO_EINVAL;
+  if (residual && (ldr & 3)) return MIMO_EINVAL;
+  if (img_bias && rows_per_img <= 0) return MIMO_EINVAL;
+  GemmArgs g{};
+  g.A = (const uint16_t*)A; g.A2 = nullptr; g.W = (const uint16_t*)W; g.out = out;
+  g.bias = bias; g.img_bias = img_bias; g.res = residual;
+  g.lda = lda; g.ldw = K; g.ldo = ldo; g.ldr = ldr; g.M = M; g.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
+  g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
+  g.nkt = (K + BK - 1) / BK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIMO_F16) return launch<MIMO_F16, false>(g, st);
+  if (dtype == MIMO_BF16) return launch<MIMO_BF16, false>(g, st);
+  return MIMO_EDTYPE;
+}
+
+extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
+                           const mimo_conv_params* p, const float* bias, const float* img_bias,
+                           const void* residual, float out_scale, unsigned flags, void* stream) {
+  if (!in || !W || !out || !p) return MIMO_EINVAL;
+  if (p->n <= 0 || p->Cin <= 0 || (p->Cin & 7) || (p->Cout & 3) || p->Cout <= 0) return MIMO_EINVAL;
+  if (!(p->ksize == 1 || p->ksize == 3) || !(p->stride == 1 || p->stride == 2)) return MIMO_EINVAL;
+  if (p->Cin2 < 0 || (p->Cin2 & 7) || (p->Cin2 > 0 && !in2)) return MIMO_EINVAL;
+  if ((p->Hup > 0) != (p->Wup > 0)) return MIMO_EINVAL;
+  if (flags & MIMO_EPI_GEGLU) return MIMO_EINVAL;
+  if (!aligned16(in) || !aligned16(W) || !aligned16(out) || (in2 && !aligned16(in2))) return MIMO_EINVAL;
+  GemmArgs g{};
+  g.A = (const uint16_t*)in; g.A2 = (const uint16_t*)in2; g.W = (const uint16_t*)W; g.out = out;
+  g.bias = bias; g.img_bias = img_bias; g.res = residual;
+  g.N = p->Cout; g.K = p->ksize * p->ksize * p->Cin + p->Cin2;
+  g.ldw = g.K; g.ldo = p->Cout; g.ldr = p->Cout; g.lda = 0;
+  g.M = (int64_t)p->n * p->Hout * p->Wout;
+  g.rows_per_img = (int64_t)p->Hout * p->Wout;
+  g.out_scale = out_scale; g.flags = flags;
+  g.Hin = p->Hin; g.Win = p->Win; g.Cin = p->Cin; g.Hout = p->Hout; g.Wout = p->Wout;
+  g.ks = p->ksize; g.stride = p->stride; g.pad_t = p->pad_t; g.pad_l = p->pad_l;
+  g.Hup = p->Hup; g.Wup = p->Wup; g.Cin2 = p->Cin2;
+  g.sh = p->Hup > 0 ? (float)p->Hin / (float)p->Hup : 1.f;
+  g.sw = p->Wup > 0 ? (float)p->Win / (float)p->Wup : 1.f;
+  g.chunks1 = (p->Cin + BK - 1) / BK;
+  g.chunks2 = (p->Cin2 + BK - 1) / BK;
+  g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIMO_F16) return launch<MIMO_F16, true>(g, st);
+  if (dtype == MIMO_BF16) return launch<MIMO_BF16, true>(g, st);
+  return MIMO_EDTYPE;
+}
+
+extern "C" int mimo_version(void) { return 1; }

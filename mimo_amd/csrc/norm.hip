@@ -1,0 +1,276 @@
+// norm.hip — HBM-bound normalisation kernels of the denoising path (gfx950).
+//   GroupNorm statistics + apply(+SiLU) over a virtual channel concat of two sources,
+//   LayerNorm (+ temporal positional-encoding add), casts.
+// Reference ops replaced: see include/mimo_hip.h.
+// All are streaming kernels: 16-byte vector loads, fp32 statistics (two-pass centred
+// variance, matching torch's numerics closely), no MFMA.
+#include "common.cuh"
+
+namespace {
+
+template <int DT>
+__device__ __forceinline__ float load_elem(const void* p, bool f32, int64_t idx) {
+  return f32 ? ((const float*)p)[idx] : HT<DT>::to_f(((const uint16_t*)p)[idx]);
+}
+
+// ---------------------------------------------------------------------------------
+// GroupNorm statistics: one block per (image, group).  Two passes over the group's
+// elements (second pass is L2-resident: a group of one image is <= HW*cpg*4 bytes).
+// ---------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, const void* x2, int C2,
+                                                       int f32, int64_t HW, int groups, float eps,
+                                                       float* stats) {
+  const int img = blockIdx.x / groups;
+  const int grp = blockIdx.x % groups;
+  const int C = C1 + C2;
+  const int cpg = C / groups;
+  const int c0 = grp * cpg;
+  const int count = (int)(HW * cpg);  // host guarantees < 2^31
+  __shared__ float red[8];
+  __shared__ float s_mean;
+
+  auto fetch = [&](int e) -> float {
+    const int p = e / cpg;
+    const int c = c0 + (e - p * cpg);
+    if (c < C1) return load_elem<DT>(x1, f32, ((int64_t)img * HW + p) * C1 + c);
+    return load_elem<DT>(x2, f32, ((int64_t)img * HW + p) * C2 + (c - C1));
+  };
+
+  float s = 0.f;
+  for (int e = threadIdx.x; e < count; e += 256) s += fetch(e);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) s_mean = (red[0] + red[1] + red[2] + red[3]) / (float)count;
+  __syncthreads();
+  const float mean = s_mean;
+  float q = 0.f;
+  for (int e = threadIdx.x; e < count; e += 256) {
+    const float d = fetch(e) - mean;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)count;
+    stats[(int64_t)blockIdx.x * 2 + 0] = mean;
+    stats[(int64_t)blockIdx.x * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// GroupNorm apply: each thread handles 8 consecutive channels of one token.
+// ---------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, int C1, const void* x2, int C2,
+                                                       int f32, int n, int64_t HW, int groups,
+                                                       const float* stats, const float* gamma,
+                                                       const float* beta, int silu, uint16_t* out,
+                                                       uint16_t* raw) {
+  const int C = C1 + C2;
+  const int cpg = C / groups;
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)n * HW * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t tok = i / c8;
+    const int c = (int)(i - tok * c8) * 8;
+    const int img = (int)(tok / HW);
+    float v[8];
+    // C1 % 8 == 0 is enforced by the host, so a chunk never straddles the two sources
+    const void* src = c < C1 ? x1 : x2;
+    const int64_t off = c < C1 ? tok * C1 + c : tok * C2 + (c - C1);
+    if (f32) {
+      const float4 a = *reinterpret_cast<const float4*>((const float*)src + off);
+      const float4 b = *reinterpret_cast<const float4*>((const float*)src + off + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const uint4 a = *reinterpret_cast<const uint4*>((const uint16_t*)src + off);
+      unpack8<DT>(a, v);
+    }
+    if (raw) *reinterpret_cast<uint4*>(raw + tok * C + c) = pack8<DT>(v);
+    if (out) {
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int grp = (c + k) / cpg;
+        const float mean = stats[((int64_t)img * groups + grp) * 2];
+        const float rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
+        float t = (v[k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        y[k] = silu ? silu_f(t) : t;
+      }
+      *reinterpret_cast<uint4*>(out + tok * C + c) = pack8<DT>(y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 64*8*4 = 2048).
+// ---------------------------------------------------------------------------------
+template <int DT, int VPL>  // VPL = 8-element vectors per lane
+__global__ __launch_bounds__(256) void layer_norm_kernel(const void* x, int f32, int64_t rows, int C,
+                                                         float eps, const float* gamma,
+                                                         const float* beta, const float* pe,
+                                                         int64_t rows_per_frame, int pe_frames,
+                                                         uint16_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c8 = C / 8;
+  float v[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int ci = lane + 64 * j;
+    if (ci < c8) {
+      if (f32) {
+        const float* p = (const float*)x + row * C + ci * 8;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
+        v[j][4] = b.x; v[j][5] = b.y; v[j][6] = b.z; v[j][7] = b.w;
+      } else {
+        unpack8<DT>(*reinterpret_cast<const uint4*>((const uint16_t*)x + row * C + ci * 8), v[j]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[j][k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int ci = lane + 64 * j;
+    if (ci < c8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[j][k] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const float* pe_row = pe ? pe + ((row / rows_per_frame) % pe_frames) * (int64_t)C : nullptr;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int ci = lane + 64 * j;
+    if (ci < c8) {
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = ci * 8 + k;
+        y[k] = (v[j][k] - mean) * rstd * gamma[c] + beta[c];
+        if (pe_row) y[k] += pe_row[c];
+      }
+      *reinterpret_cast<uint4*>(out + row * C + ci * 8) = pack8<DT>(y);
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void cast_kernel(const void* in, int f32, int64_t count8, uint16_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    if (f32) {
+      const float4 a = *reinterpret_cast<const float4*>((const float*)in + i * 8);
+      const float4 b = *reinterpret_cast<const float4*>((const float*)in + i * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      unpack8<DT>(*reinterpret_cast<const uint4*>((const uint16_t*)in + i * 8), v);
+    }
+    *reinterpret_cast<uint4*>(out + i * 8) = pack8<DT>(v);
+  }
+}
+
+inline unsigned stream_grid(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_is_f32,
+                                     int dtype, int n, int64_t HW, int groups, float eps, float* stats,
+                                     void* stream) {
+  if (!x1 || !stats || n <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
+  if ((C1 + C2) % groups) return MIMO_EINVAL;
+  if (C2 > 0 && !x2) return MIMO_EINVAL;
+  if (HW * ((C1 + C2) / groups) >= 0x7fffffffLL) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(n * groups);
+  if (dtype == MIMO_F16)
+    hipLaunchKernelGGL(gn_stats_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats);
+  else if (dtype == MIMO_BF16)
+    hipLaunchKernelGGL(gn_stats_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats);
+  else
+    return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32,
+                                     int dtype, int n, int64_t HW, int groups, const float* stats,
+                                     const float* gamma, const float* beta, int silu, void* out,
+                                     void* raw_out, void* stream) {
+  if (!x1 || n <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
+  if ((C1 & 7) || (C2 & 7) || (C1 + C2) % groups) return MIMO_EINVAL;
+  if (C2 > 0 && !x2) return MIMO_EINVAL;
+  if (out && (!stats || !gamma || !beta)) return MIMO_EINVAL;
+  if (!out && !raw_out) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = stream_grid((int64_t)n * HW * ((C1 + C2) / 8));
+  if (dtype == MIMO_F16)
+    hipLaunchKernelGGL(gn_apply_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, (uint16_t*)raw_out);
+  else if (dtype == MIMO_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, (uint16_t*)raw_out);
+  else
+    return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C, float eps,
+                               const float* gamma, const float* beta, const float* pe,
+                               int64_t rows_per_frame, int pe_frames, void* out, void* stream) {
+  if (!x || !out || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 2048) return MIMO_EINVAL;
+  if (pe && (rows_per_frame <= 0 || pe_frames <= 0)) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int vpl = (C / 8 + 63) / 64;
+#define LN_LAUNCH(DT, V)                                                                              \
+  hipLaunchKernelGGL((layer_norm_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x, x_is_f32, rows, C, \
+                     eps, gamma, beta, pe, rows_per_frame, pe_frames, (uint16_t*)out)
+  if (dtype == MIMO_F16) {
+    if (vpl == 1) LN_LAUNCH(MIMO_F16, 1); else if (vpl == 2) LN_LAUNCH(MIMO_F16, 2);
+    else if (vpl == 3) LN_LAUNCH(MIMO_F16, 3); else LN_LAUNCH(MIMO_F16, 4);
+  } else if (dtype == MIMO_BF16) {
+    if (vpl == 1) LN_LAUNCH(MIMO_BF16, 1); else if (vpl == 2) LN_LAUNCH(MIMO_BF16, 2);
+    else if (vpl == 3) LN_LAUNCH(MIMO_BF16, 3); else LN_LAUNCH(MIMO_BF16, 4);
+  } else {
+    return MIMO_EDTYPE;
+  }
+#undef LN_LAUNCH
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_cast(const void* in, int in_is_f32, int dtype, int64_t count, void* out_half,
+                         void* stream) {
+  if (!in || !out_half || count <= 0 || (count & 7)) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = stream_grid(count / 8);
+  if (dtype == MIMO_F16)
+    hipLaunchKernelGGL(cast_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, in, in_is_f32, count / 8, (uint16_t*)out_half);
+  else if (dtype == MIMO_BF16)
+    hipLaunchKernelGGL(cast_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, in, in_is_f32, count / 8, (uint16_t*)out_half);
+  else
+    return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}

@@ -1,0 +1,76 @@
+"""ctypes binding of libmimo_hip.so (the C-ABI declared in include/mimo_hip.h).
+
+This is the ONLY compute path of the package: there is no PyTorch/CPU fallback.  If the
+shared library is missing the import of any op raises; if an entry point rejects its
+arguments a `MimoHipError` is raised with the C error code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
+
+F16, BF16 = 0, 1
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32 = 1, 2, 4, 8
+
+c_vp, c_i, c_i64, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint
+
+
+class ConvParams(ctypes.Structure):
+    _fields_ = [(n, c_i) for n in ("n", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ksize", "stride",
+                                   "pad_t", "pad_l", "Hup", "Wup", "Cin2")]
+
+
+# name -> argtypes, mirrors include/mimo_hip.h one to one
+SIGNATURES = {
+    "mimo_version": [],
+    "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_f, c_u, c_vp],
+    "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp],
+    "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
+    "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
+    "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp],
+    "mimo_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                       c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
+    "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
+    "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
+    "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],
+    "mimo_tokens_to_ncfhw": [c_vp, c_i, c_i, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp],
+    "mimo_cast": [c_vp, c_i, c_i, c_i64, c_vp, c_vp],
+    "mimo_cfg_ddim_step": [c_vp, c_vp, c_vp, c_i, c_i, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_vp],
+    "mimo_window_accumulate": [c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_i64, c_vp, c_vp, c_vp],
+    "mimo_tokens_to_image": [c_vp, c_i, c_i, c_i64, c_i, c_i, c_i, c_vp, c_vp],
+}
+
+
+class MimoHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MimoHipError(
+            f"{LIB_PATH} is missing: build it with `python -m mimo_amd.build` "
+            "(hipcc, gfx950). mimo_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise MimoHipError(f"{name} failed with code {rc}"
+                           + (" (MIMO_EINVAL)" if rc == -1 else " (MIMO_EDTYPE)" if rc == -2 else
+                              f" (hipError_t {rc})" if rc > 0 else ""))
+    return rc

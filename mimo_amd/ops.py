@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the C-ABI (mimo_amd.lib): torch is used only to own device
+memory and the stream; every op below is ONE call into libmimo_hip.so.
+
+Activation convention: channels-last token-major.  An image batch is a contiguous tensor
+[n, H, W, C] (equivalently [n*H*W, C]); the residual stream is fp32, MFMA operands are
+fp16/bf16 ("half16").
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.float16: L.F16, torch.bfloat16: L.BF16}
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise L.MimoHipError(f"compute dtype must be float16 or bfloat16, got {dtype}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if not t.is_cuda:
+        raise L.MimoHipError(f"{name} must be a device tensor: mimo_amd has no CPU path")
+
+
+def _is_f32(t):
+    if t.dtype == torch.float32:
+        return 1
+    if t.dtype in _DT:
+        return 0
+    raise L.MimoHipError(f"unsupported tensor dtype {t.dtype}")
+
+
+def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f32=False, silu=False,
+         geglu=False, out=None, out_scale=1.0):
+    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1)."""
+    _chk(a, "a")
+    assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
+    assert a.dtype == w.dtype
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    assert out.stride(1) == 1
+    flags = (L.EPI_SILU if silu else 0) | (L.EPI_GEGLU if geglu else 0) | \
+            (L.EPI_OUT_F32 if out.dtype == torch.float32 else 0)
+    ldr = 0
+    if residual is not None:
+        assert residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[0] == M
+        flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
+        ldr = residual.stride(0)
+    L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
+           out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), rows_per_img, _ptr(residual), ldr,
+           float(out_scale), flags, _stream())
+    return out
+
+
+def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
+           img_bias=None, residual=None, out_f32=False, silu=False, out_scale=1.0):
+    """Channels-last implicit-GEMM conv.  x: half [n, H, W, Cin]; w: packed half [cout, ks*ks*Cin (+Cin2)].
+
+    pad = (pad_top, pad_left); default (ks//2, ks//2).  out_hw defaults to the torch formula for
+    symmetric padding.  upsample_to = (Hup, Wup) applies nearest-neighbour upsampling first.
+    x2: optional half [n, Hout, Wout, Cin2] fused as an extra 1x1 tap (ResBlock shortcut).
+    """
+    _chk(x, "x")
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous()
+    n, H, W, cin = x.shape
+    if pad is None:
+        pad = (ksize // 2, ksize // 2)
+    Hv, Wv = (upsample_to if upsample_to is not None else (H, W))
+    if out_hw is None:
+        out_hw = ((Hv + 2 * pad[0] - ksize) // stride + 1, (Wv + 2 * pad[1] - ksize) // stride + 1)
+    Ho, Wo = out_hw
+    cin2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:3] == (n, Ho, Wo)
+        cin2 = x2.shape[3]
+    assert w.shape == (cout, ksize * ksize * cin + cin2), (w.shape, cout, ksize, cin, cin2)
+    p = L.ConvParams(n, H, W, cin, Ho, Wo, cout, ksize, stride, pad[0], pad[1],
+                     Hv if upsample_to is not None else 0, Wv if upsample_to is not None else 0, cin2)
+    out = torch.empty((n, Ho, Wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    flags = (L.EPI_SILU if silu else 0) | (L.EPI_OUT_F32 if out_f32 else 0)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == out.shape
+        flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
+    L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
+           ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags, _stream())
+    return out
+
+
+def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dtype=None, want_raw=False,
+               want_norm=True):
+    """GroupNorm(+SiLU) over the virtual channel concat [x1 | x2]; inputs [n, H, W, C*] fp32 or half.
+
+    Returns (normed_half or None, raw_half or None)."""
+    _chk(x1, "x1")
+    assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
+    n = x1.shape[0]
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    HW = x1.numel() // (n * C1)
+    if dtype is None:
+        dtype = x1.dtype if x1.dtype in _DT else torch.float16
+    f32 = _is_f32(x1)
+    if x2 is not None:
+        assert _is_f32(x2) == f32 and x2.numel() // (n * C2) == HW
+    shape = tuple(x1.shape[:-1]) + (C1 + C2,)
+    out = raw = stats = None
+    if want_norm:
+        stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
+        L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
+               float(eps), stats.data_ptr(), _stream())
+        out = torch.empty(shape, device=x1.device, dtype=dtype)
+    if want_raw:
+        raw = torch.empty(shape, device=x1.device, dtype=dtype)
+    L.call("mimo_group_norm_apply", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
+           _ptr(stats), _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(raw), _stream())
+    return out, raw
+
+
+def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0):
+    """LayerNorm over the last dim of x [rows, C] -> half; optional + pe[(row // rows_per_frame) % pe_frames]."""
+    _chk(x, "x")
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if dtype is None:
+        dtype = x.dtype if x.dtype in _DT else torch.float16
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    L.call("mimo_layer_norm", x.data_ptr(), _is_f32(x), dt_code(dtype), rows, C, float(eps), gamma.data_ptr(),
+           beta.data_ptr(), _ptr(pe), rows_per_frame, pe_frames, out.data_ptr(), _stream())
+    return out
+
+
+def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=None):
+    """Multi-head attention.  q: [B, Nq, C] view, k/v: [B, Nk, C] views (last stride 1, batch stride =
+    N * row stride); optional shared second segment k2/v2: [Nk2, C] views for batches >= seg2_first_batch."""
+    _chk(q, "q")
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    for t, N in ((q, Nq), (k, Nk), (v, Nk)):
+        assert t.stride(2) == 1 and (B == 1 or t.stride(0) == N * t.stride(1)), (t.shape, t.stride())
+    Nk2 = 0
+    ldk2 = ldv2 = 0
+    if k2 is not None:
+        Nk2 = k2.shape[0]
+        assert k2.stride(1) == 1 and v2.stride(1) == 1
+        ldk2, ldv2 = k2.stride(0), v2.stride(0)
+    out = torch.empty((B, Nq, C), device=q.device, dtype=q.dtype)
+    if scale is None:
+        scale = d ** -0.5
+    L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
+           v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
+           seg2_first_batch, heads, d, float(scale), _stream())
+    return out
+
+
+def temporal_attention(q, k, v, b, F, HW, heads, *, scale=None):
+    """Attention over the F frames of each (batch, pixel, head); q/k/v: [b*F*HW, C] views (last stride 1)."""
+    _chk(q, "q")
+    C = q.shape[-1]
+    d = C // heads
+    assert q.shape[0] == b * F * HW and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    out = torch.empty((q.shape[0], C), device=q.device, dtype=q.dtype)
+    if scale is None:
+        scale = d ** -0.5
+    L.call("mimo_temporal_attention", dt_code(q.dtype), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0),
+           v.data_ptr(), v.stride(0), out.data_ptr(), C, b, F, HW, heads, d, float(scale), _stream())
+    return out
+
+
+def softmax_rows(x, dtype, scale=1.0):
+    _chk(x, "x")
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    L.call("mimo_softmax_rows", dt_code(dtype), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+           x.shape[0], x.shape[1], float(scale), _stream())
+    return out
+
+
+def ncfhw_to_tokens(x, dtype, *, frame_idx=None, cpad=None, out=None, out_col0=0):
+    """[b, C, F, H, W] (fp32/half) -> half tokens [b*F', H, W, cpad]; frame_idx: int32 device tensor."""
+    _chk(x, "x")
+    assert x.dim() == 5 and x.is_contiguous()
+    b, C, F, H, W = x.shape
+    Fsel = F if frame_idx is None else frame_idx.numel()
+    if cpad is None:
+        cpad = C
+    if out is None:
+        out = torch.empty((b * Fsel, H, W, cpad), device=x.device, dtype=dtype)
+    assert out.is_contiguous() and out.dtype == dtype
+    L.call("mimo_ncfhw_to_tokens", x.data_ptr(), _is_f32(x), dt_code(dtype), b, C, F, H, W, _ptr(frame_idx), Fsel,
+           cpad, out.shape[-1], out_col0, out.data_ptr(), _stream())
+    return out
+
+
+def tokens_to_ncfhw(tok, b, C, F, H, W, *, scale=1.0):
+    """tokens [b*F, H, W, ld] -> fp32 [b, C, F, H, W] (channels [0, C))."""
+    _chk(tok, "tok")
+    assert tok.is_contiguous()
+    ld = tok.shape[-1]
+    dt = tok.dtype if tok.dtype in _DT else torch.float16
+    out = torch.empty((b, C, F, H, W), device=tok.device, dtype=torch.float32)
+    L.call("mimo_tokens_to_ncfhw", tok.data_ptr(), _is_f32(tok), dt_code(dt), ld, b, C, F, H, W, float(scale),
+           out.data_ptr(), _stream())
+    return out
+
+
+def tokens_to_image(tok, n, H, W):
+    """tokens [n, H, W, ld>=3] -> fp32 [n, 3, H, W] = clamp(x/2 + 0.5, 0, 1)."""
+    _chk(tok, "tok")
+    assert tok.is_contiguous()
+    dt = tok.dtype if tok.dtype in _DT else torch.float16
+    out = torch.empty((n, 3, H, W), device=tok.device, dtype=torch.float32)
+    L.call("mimo_tokens_to_image", tok.data_ptr(), _is_f32(tok), dt_code(dt), tok.shape[-1], n, H, W,
+           out.data_ptr(), _stream())
+    return out
+
+
+def cast_half(x, dtype):
+    _chk(x, "x")
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    L.call("mimo_cast", x.data_ptr(), _is_f32(x), dt_code(dtype), x.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def window_accumulate(pred_tok, frames, acc, counter):
+    """acc[:, :, frames[j]] += pred[:, :, j]; counter[frames[j]] += 1.
+    pred_tok: fp32 tokens [bb*Fw, H, W, ld]; acc: fp32 [bb, C, F, H, W]; counter fp32 [F]."""
+    _chk(pred_tok, "pred_tok")
+    assert pred_tok.dtype == torch.float32 and pred_tok.is_contiguous() and acc.is_contiguous()
+    bb, C, F, H, W = acc.shape
+    Fw = frames.numel()
+    L.call("mimo_window_accumulate", pred_tok.data_ptr(), pred_tok.shape[-1], frames.data_ptr(), Fw, bb, C, F,
+           H * W, acc.data_ptr(), counter.data_ptr(), _stream())
+
+
+def cfg_ddim_step(acc, counter, latents, cfg, guidance, sa, s1, sap, s1p):
+    """In-place: latents <- DDIM(v-pred) step of CFG-combined, window-averaged prediction."""
+    _chk(latents, "latents")
+    assert latents.dtype == torch.float32 and latents.is_contiguous() and acc.is_contiguous()
+    _, C, F, H, W = latents.shape
+    L.call("mimo_cfg_ddim_step", acc.data_ptr(), counter.data_ptr(), latents.data_ptr(), C, F, H * W, int(cfg),
+           float(guidance), float(sa), float(s1), float(sap), float(s1p), _stream())

@@ -1,0 +1,43 @@
+"""Weight re-layouts from the reference checkpoint layout (torch nn.Module state-dict tensors)
+to what the gfx950 kernels consume.  Done once per loaded state dict, on the device."""
+import torch
+
+
+def pack_conv(weight, dtype, shortcut=None, cin_pad=None, cout_pad=None):
+    """nn.Conv2d weight [Cout, Cin, kh, kw] -> [Cout(+pad), kh*kw*Cin(+pad) (+ Cin2)], K index = (ky*kw + kx)*Cin + ci.
+
+    shortcut: optional 1x1 conv weight [Cout, Cin2, 1, 1] appended as an extra tap (fused ResBlock shortcut).
+    cin_pad / cout_pad: zero-pad channels (thin first/last convs: Cin must be a multiple of 8, Cout of 4)."""
+    co, ci, kh, kw = weight.shape
+    w = weight.detach().float().permute(0, 2, 3, 1)  # [co, kh, kw, ci]
+    if cin_pad is not None and cin_pad > ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+    w = w.reshape(co, -1)
+    if shortcut is not None:
+        w = torch.cat([w, shortcut.detach().float().reshape(co, -1)], dim=1)
+    if cout_pad is not None and cout_pad > co:
+        w = torch.nn.functional.pad(w, (0, 0, 0, cout_pad - co))
+    return w.to(dtype).contiguous()
+
+
+def pad_vec(v, n):
+    v = v.detach().float()
+    if v.numel() < n:
+        v = torch.nn.functional.pad(v, (0, n - v.numel()))
+    return v.contiguous()
+
+
+def pack_geglu(weight, bias, dtype):
+    """GEGLU proj Linear(dim, 2*inner): rows [0, inner) = value, [inner, 2*inner) = gate
+    (diffusers GEGLU: hidden, gate = proj(x).chunk(2)).  Interleave in blocks of 16 rows
+    [16 value | 16 gate] so one wave holds matching value/gate MFMA tiles."""
+    two_inner, dim = weight.shape
+    inner = two_inner // 2
+    assert inner % 16 == 0
+    w = weight.detach().float()
+    wv = w[:inner].reshape(inner // 16, 16, dim)
+    wg = w[inner:].reshape(inner // 16, 16, dim)
+    wp = torch.stack([wv, wg], dim=1).reshape(two_inner, dim)
+    b = bias.detach().float()
+    bp = torch.stack([b[:inner].reshape(-1, 16), b[inner:].reshape(-1, 16)], dim=1).reshape(two_inner)
+    return wp.to(dtype).contiguous(), bp.contiguous()

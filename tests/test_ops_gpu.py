@@ -1,0 +1,294 @@
+"""Kernel-level parity: every HIP entry point (through the C-ABI) vs a plain PyTorch fp32
+reference of the same op, on identical half-rounded inputs.  Tolerances are rel-L2 and written
+per test: fp32-out kernels only differ by accumulation order; half-out kernels add one rounding
+(fp16 eps 4.9e-4, bf16 eps 3.9e-3)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+OUT_TOL = {torch.float16: 6e-4, torch.bfloat16: 5e-3}  # one output rounding
+ACC_TOL = 2e-5  # fp32 output, same rounded inputs
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 320), (1000, 128, 200), (77, 36, 72), (4096, 640, 1280), (257, 2560, 320)])
+def test_gemm_plain_and_epilogues(dev, dtype, M, N, K):
+    from mimo_amd import ops
+    a = rnd((M, K), dev, dtype, 1)
+    w = rnd((N, K), dev, dtype, 2, K ** -0.5)  # asymmetric, non-square
+    bias = rnd((N,), dev, torch.float32, 3)
+    res = rnd((M, N), dev, torch.float32, 4)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w, out_f32=True)
+    assert rel_l2(out, ref) < ACC_TOL
+    out = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+    assert rel_l2(out, ref + bias + res) < ACC_TOL
+    out = ops.gemm(a, w, bias=bias, silu=True)
+    assert out.dtype == dtype
+    assert rel_l2(out.float(), F.silu(ref + bias)) < OUT_TOL[dtype]
+    # per-image bias + half residual + scale
+    rpi = 7 if M % 7 == 0 else M
+    ib = rnd((M // rpi, N), dev, torch.float32, 5)
+    resh = res.to(dtype)
+    out = ops.gemm(a, w, img_bias=ib, rows_per_img=rpi, residual=resh, out_f32=True, out_scale=0.5)
+    assert rel_l2(out, 0.5 * (ref + ib.repeat_interleave(rpi, 0) + resh.float())) < ACC_TOL
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_strided_a_view(dev, dtype):
+    from mimo_amd import ops
+    big = rnd((200, 3 * 64), dev, dtype, 1)
+    w = rnd((96, 64), dev, dtype, 2, 0.1)
+    out = ops.gemm(big[:, 64:128], w, out_f32=True)
+    assert rel_l2(out, big[:, 64:128].float() @ w.float().t()) < ACC_TOL
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,dim", [(256, 320), (130, 64)])
+def test_gemm_geglu(dev, dtype, M, dim):
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_geglu
+    inner = 4 * dim
+    x = rnd((M, dim), dev, dtype, 1)
+    w = rnd((2 * inner, dim), dev, dtype, 2, dim ** -0.5)
+    b = rnd((2 * inner,), dev, torch.float32, 3, 0.1)
+    wp, bp = pack_geglu(w, b, dtype)
+    out = ops.gemm(x, wp, bias=bp, geglu=True)
+    assert out.shape == (M, inner)
+    h = x.float() @ w.float().t() + b
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
+
+
+CONV_CASES = [
+    # n, H, W, Cin, Cout, ks, stride, pad(t,l), out_hw, upsample_to
+    (2, 16, 16, 64, 160, 3, 1, None, None, None),
+    (3, 9, 7, 320, 320, 3, 1, None, None, None),       # odd spatial
+    (2, 16, 16, 96, 64, 3, 2, None, None, None),        # stride 2, Cin not multiple of 64
+    (2, 8, 8, 64, 128, 3, 1, None, None, (16, 16)),     # nearest x2 then conv
+    (2, 13, 13, 64, 64, 3, 1, None, None, (25, 25)),    # explicit-size nearest (784 path: 13 -> 25)
+    (1, 16, 16, 128, 128, 3, 2, (0, 0), (8, 8), None),  # VAE asymmetric pad (0,1,0,1) + stride 2
+    (2, 8, 8, 8, 320, 3, 1, None, None, None),          # thin Cin (conv_in)
+    (2, 8, 8, 320, 4, 3, 1, None, None, None),          # thin Cout (conv_out)
+    (2, 8, 8, 64, 64, 1, 1, None, None, None),          # 1x1
+]
+
+
+def torch_conv_ref(x, w, b, ks, stride, pad, out_hw, upsample_to):
+    xt = x.float().permute(0, 3, 1, 2)
+    if upsample_to is not None:
+        xt = F.interpolate(xt, size=upsample_to, mode="nearest")
+    if pad == (0, 0) and stride == 2:
+        xt = F.pad(xt, (0, 1, 0, 1))
+        y = F.conv2d(xt, w.float(), b, stride=2, padding=0)
+    else:
+        y = F.conv2d(xt, w.float(), b, stride=stride, padding=ks // 2)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(dev, dtype, case):
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv
+    n, H, W, cin, cout, ks, stride, pad, out_hw, up = case
+    x = rnd((n, H, W, cin), dev, dtype, 1)
+    w = rnd((cout, cin, ks, ks), dev, dtype, 2, (cin * ks * ks) ** -0.5)
+    b = rnd((cout,), dev, torch.float32, 3)
+    ref = torch_conv_ref(x, w, b, ks, stride, pad, out_hw, up)
+    out = ops.conv2d(x, pack_conv(w, dtype), cout, ksize=ks, stride=stride, pad=pad, out_hw=out_hw,
+                     upsample_to=up, bias=b, out_f32=True)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < ACC_TOL
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_resblock_epilogue_and_fused_shortcut(dev, dtype):
+    """conv2 of a ResBlock: 3x3 over h + fused 1x1 shortcut over x + per-image temb-style bias + fp32 residual."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv
+    n, H, W, cin, cout, cx = 3, 8, 8, 128, 160, 192
+    h = rnd((n, H, W, cin), dev, dtype, 1)
+    x = rnd((n, H, W, cx), dev, dtype, 2)
+    w = rnd((cout, cin, 3, 3), dev, dtype, 3, (9 * cin) ** -0.5)
+    ws = rnd((cout, cx, 1, 1), dev, dtype, 4, cx ** -0.5)
+    b = rnd((cout,), dev, torch.float32, 5)
+    temb = rnd((n, cout), dev, torch.float32, 6)
+    res = rnd((n, H, W, cout), dev, torch.float32, 7)
+    ref = torch_conv_ref(h, w, b, 3, 1, None, None, None) + \
+        F.conv2d(x.float().permute(0, 3, 1, 2), ws.float()).permute(0, 2, 3, 1) + temb[:, None, None, :] + res
+    out = ops.conv2d(h, pack_conv(w, dtype, shortcut=ws), cout, x2=x, bias=b, img_bias=temb, residual=res,
+                     out_f32=True)
+    assert rel_l2(out, ref) < ACC_TOL
+    out = ops.conv2d(h, pack_conv(w, dtype), cout, bias=b, silu=True)
+    assert rel_l2(out.float(), F.silu(torch_conv_ref(h, w, b, 3, 1, None, None, None))) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("f32in", [True, False])
+@pytest.mark.parametrize("C1,C2,eps,silu", [(320, 0, 1e-5, True), (1280, 640, 1e-5, True), (320, 640, 1e-6, False), (128, 0, 1e-6, True)])
+def test_group_norm_concat(dev, dtype, f32in, C1, C2, eps, silu):
+    from mimo_amd import ops
+    n, H, W = 3, 6, 5
+    idt = torch.float32 if f32in else dtype
+    x1 = (rnd((n, H, W, C1), dev, torch.float32, 1) * 2 + 0.7).to(idt)
+    x2 = (rnd((n, H, W, C2), dev, torch.float32, 2) - 0.3).to(idt) if C2 else None
+    C = C1 + C2
+    gamma = rnd((C,), dev, torch.float32, 3) * 0.1 + 1
+    beta = rnd((C,), dev, torch.float32, 4) * 0.1
+    out, raw = ops.group_norm(x1, gamma, beta, eps=eps, silu=silu, x2=x2, dtype=dtype, want_raw=True)
+    cat = torch.cat([x1, x2], dim=-1) if C2 else x1
+    ref = F.group_norm(cat.float().permute(0, 3, 1, 2), 32, gamma, beta, eps).permute(0, 2, 3, 1)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
+    assert torch.equal(raw, cat.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [320, 640, 1280])
+def test_layer_norm_and_pe(dev, dtype, C):
+    from mimo_amd import ops
+    Fr, HW = 5, 6
+    x = rnd((2 * Fr * HW, C), dev, torch.float32, 1) * 1.5 + 0.2
+    g = rnd((C,), dev, torch.float32, 2) * 0.1 + 1
+    b = rnd((C,), dev, torch.float32, 3) * 0.1
+    out = ops.layer_norm(x, g, b, dtype=dtype)
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
+    pe = rnd((32, C), dev, torch.float32, 4)
+    out = ops.layer_norm(x, g, b, dtype=dtype, pe=pe, rows_per_frame=HW, pe_frames=Fr)
+    fidx = (torch.arange(2 * Fr * HW, device=dev) // HW) % Fr
+    assert rel_l2(out.float(), ref + pe[fidx]) < OUT_TOL[dtype]
+
+
+def sdpa_ref(q, k, v, heads):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.float().reshape(B, Nq, heads, d).transpose(1, 2)
+    kh = k.float().reshape(B, -1, heads, d).transpose(1, 2)
+    vh = v.float().reshape(B, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,N,Nb", [(40, 256, 256), (80, 100, 100), (160, 64, 64), (40, 130, 70), (64, 200, 0)])
+def test_attention_self_plus_bank(dev, dtype, d, N, Nb):
+    """cond rows (b >= 2) attend [self || bank]; uncond rows (b < 2) attend self — one launch."""
+    from mimo_amd import ops
+    heads, B = 4, 4
+    C = heads * d
+    qkv = rnd((B, N, 3 * C), dev, dtype, 1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    if Nb:
+        bank = rnd((Nb, 2 * C), dev, dtype, 2)
+        k2, v2 = bank[:, :C], bank[:, C:]
+        out = ops.attention(q, k, v, heads, k2=k2, v2=v2, seg2_first_batch=2)
+        ref_u = sdpa_ref(q[:2], k[:2], v[:2], heads)
+        kc = torch.cat([k[2:], k2[None].expand(2, -1, -1)], dim=1)
+        vc = torch.cat([v[2:], v2[None].expand(2, -1, -1)], dim=1)
+        ref = torch.cat([ref_u, sdpa_ref(q[2:], kc, vc, heads)], dim=0)
+    else:
+        out = ops.attention(q, k, v, heads)
+        ref = sdpa_ref(q, k, v, heads)
+    assert rel_l2(out.float(), ref) < 2.5 * OUT_TOL[dtype]  # P is rounded to half before P.V
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_forced_rescale(dev, dtype):
+    """Spike a late key so the running max jumps in a later KV tile (online-softmax rescale path)."""
+    from mimo_amd import ops
+    heads, d, N = 2, 40, 192
+    C = heads * d
+    q = rnd((1, N, C), dev, dtype, 1)
+    k = rnd((1, N, C), dev, dtype, 2)
+    v = rnd((1, N, C), dev, dtype, 3)
+    k[0, 150] = (q[0, 7].float() * 3).to(dtype)  # huge score for query 7 at key 150 (third tile)
+    out = ops.attention(q, k, v, heads)
+    assert rel_l2(out.float(), sdpa_ref(q, k, v, heads)) < 2.5 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,Fr,HW", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 5), (160, 3, 7)])
+def test_temporal_attention(dev, dtype, d, Fr, HW):
+    from mimo_amd import ops
+    heads, b = 8, 2
+    C = heads * d
+    qkv = rnd((b * Fr * HW, 3 * C), dev, dtype, 1)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    out = ops.temporal_attention(q, k, v, b, Fr, HW, heads)
+
+    def to_seq(t):  # "(b f) d c -> (b d) f c"
+        return t.float().reshape(b, Fr, HW, C).permute(0, 2, 1, 3).reshape(b * HW, Fr, C)
+
+    ref = sdpa_ref(to_seq(q), to_seq(k), to_seq(v), heads)
+    ref = ref.reshape(b, HW, Fr, C).permute(0, 2, 1, 3).reshape(b * Fr * HW, C)
+    assert rel_l2(out.float(), ref) < 2.5 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows(dev, dtype):
+    from mimo_amd import ops
+    x = rnd((37, 1000), dev, torch.float32, 1) * 3
+    out = ops.softmax_rows(x, dtype, scale=0.3)
+    assert rel_l2(out.float(), torch.softmax(x * 0.3, -1)) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_roundtrip_and_gather(dev, dtype):
+    from mimo_amd import ops
+    b, C, Fr, H, W = 2, 4, 6, 5, 3
+    x = rnd((b, C, Fr, H, W), dev, torch.float32, 1)
+    idx = torch.tensor([4, 5, 0, 1], dtype=torch.int32, device=dev)
+    tok = ops.ncfhw_to_tokens(x, dtype, frame_idx=idx, cpad=8)
+    assert tok.shape == (b * 4, H, W, 8)
+    ref = x[:, :, idx.long()].permute(0, 2, 3, 4, 1).reshape(b * 4, H, W, C).to(dtype)
+    assert torch.equal(tok[..., :C], ref) and torch.count_nonzero(tok[..., C:]) == 0
+    back = ops.tokens_to_ncfhw(tok, b, C, 4, H, W, scale=2.0)
+    assert torch.allclose(back, 2.0 * x[:, :, idx.long()].to(dtype).float())
+    img = ops.tokens_to_image(tok.float().contiguous(), b * 4, H, W)
+    assert torch.allclose(img, (tok[..., :3].float() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2))
+
+
+def test_window_accumulate_and_cfg_ddim(dev):
+    from mimo_amd import ops
+    C, Fr, H, W, Fw = 4, 10, 4, 4, 6
+    lat = rnd((1, C, Fr, H, W), dev, torch.float32, 1)
+    acc = torch.zeros((2, C, Fr, H, W), device=dev)
+    cnt = torch.zeros((Fr,), device=dev)
+    acc_ref, cnt_ref = acc.clone(), cnt.clone()
+    for s, frames in enumerate([[0, 1, 2, 3, 4, 5], [4, 5, 6, 7, 8, 9], [8, 9, 0, 1, 2, 3]]):
+        pred = rnd((2 * Fw, H, W, 4), dev, torch.float32, 10 + s)
+        fi = torch.tensor(frames, dtype=torch.int32, device=dev)
+        ops.window_accumulate(pred, fi, acc, cnt)
+        p5 = pred.reshape(2, Fw, H, W, C).permute(0, 4, 1, 2, 3)
+        acc_ref[:, :, fi.long()] += p5
+        cnt_ref[fi.long()] += 1
+    assert torch.equal(acc, acc_ref) and torch.equal(cnt, cnt_ref)
+    g, sa, s1, sap, s1p = 3.5, 0.6, 0.8, 0.9, math.sqrt(1 - 0.81)
+    lat2 = lat.clone()
+    ops.cfg_ddim_step(acc, cnt, lat2, True, g, sa, s1, sap, s1p)
+    npred = acc_ref / cnt_ref[None, None, :, None, None]
+    npred = npred[0:1] + g * (npred[1:2] - npred[0:1])
+    x0 = sa * lat - s1 * npred
+    eps = sa * npred + s1 * lat
+    assert torch.allclose(lat2, sap * x0 + s1p * eps, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,81 @@
+"""Per-kernel micro-benchmarks at the config-2 shapes of the denoising UNet.
+Usage (GPU box): python tools/microbench.py [--dtype fp16|bf16]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mimo_amd import ops  # noqa: E402
+from mimo_amd.packing import pack_conv, pack_geglu  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    dev = torch.device("cuda:0")
+    n = 48
+    print(f"# dtype={a.dtype} device={torch.cuda.get_device_name(0)}")
+    # --- 3x3 convs (n, hw, cin, cout)
+    for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
+        x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
+        w = pack_conv(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, dt)
+        b = torch.zeros(cout, device=dev)
+        t = timeit(lambda: ops.conv2d(x, w, cout, bias=b, out_f32=True))
+        fl = 2 * n * hw * hw * cout * 9 * cin
+        print(f"conv3x3 n{n} {hw}x{hw} {cin}->{cout}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
+    # --- GEMMs (M, N, K)
+    for (M, N, K) in [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
+        A = torch.randn(M, K, device=dev).to(dt)
+        W = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+        t = timeit(lambda: ops.gemm(A, W))
+        print(f"gemm M{M} N{N} K{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s")
+    for (M, dim) in [(196608, 320), (49152, 640), (12288, 1280)]:
+        A = torch.randn(M, dim, device=dev).to(dt)
+        wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
+        t = timeit(lambda: ops.gemm(A, wp, bias=bp, geglu=True))
+        print(f"geglu-ff1 M{M} dim{dim}: {t*1e3:8.3f} ms  {2*M*8*dim*dim/t/1e12:7.1f} TF/s")
+    # --- spatial attention, 24 uncond + 24 cond (bank)
+    for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
+        qkv = torch.randn(n, N, 3 * C, device=dev).to(dt)
+        bank = torch.randn(N, 2 * C, device=dev).to(dt)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        t = timeit(lambda: ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=24))
+        fl = 4 * N * C * (24 * N + 24 * 2 * N)
+        print(f"attn N{N} C{C} d{C//8}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
+    # --- temporal attention
+    for (HW, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
+        qkv = torch.randn(2 * 24 * HW, 3 * C, device=dev).to(dt)
+        t = timeit(lambda: ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], 2, 24, HW, 8))
+        by = qkv.numel() * 2 + qkv.shape[0] * C * 2
+        print(f"temporal HW{HW} C{C}: {t*1e3:8.3f} ms  {by/t/1e9:7.1f} GB/s")
+    # --- norms
+    for (hw, C) in [(64, 320), (32, 640), (16, 1280)]:
+        x = torch.randn(n, hw, hw, C, device=dev)
+        g = torch.ones(C, device=dev)
+        b = torch.zeros(C, device=dev)
+        t = timeit(lambda: ops.group_norm(x, g, b, silu=True, dtype=dt))
+        print(f"groupnorm+silu n{n} {hw}x{hw} C{C}: {t*1e3:8.3f} ms  {x.numel()*(4+4+2)/t/1e9:7.1f} GB/s(2R+1W)")
+        t = timeit(lambda: ops.layer_norm(x.view(-1, C), g, b, dtype=dt))
+        print(f"layernorm rows{n*hw*hw} C{C}: {t*1e3:8.3f} ms  {x.numel()*6/t/1e9:7.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
