@@ -57,14 +57,15 @@ int mimo_version(void);
  *     time embedding + time_emb_proj        (src/models/unet_3d_edit_bkfill.py:462-468, src/models/resnet.py:226)
  *   A: half16 row-major, leading dimension lda (elements).  W: half16 [N,K] row-major
  *   (torch Linear.weight layout).  K % 8 == 0, lda % 8 == 0, 16-byte aligned pointers.
- *   epilogue: v = acc; +bias[n] (fp32, nullable); +img_bias[(m / rows_per_img), n]
- *   (fp32 [M/rows_per_img, N], nullable); SILU; +residual[m, ldr] (nullable); *out_scale;
- *   store to out[m, ldo].
+ *   epilogue: v = acc; +bias[n] (fp32, nullable); +img_bias[(m / rows_per_img) * img_bias_ld + n]
+ *   (fp32, nullable; one row per group of rows_per_img consecutive output rows: the
+ *   time-embedding projection / collapsed 1-key cross-attention of a batch element);
+ *   SILU; +residual[m, ldr] (nullable); *out_scale; store to out[m, ldo].
  * --------------------------------------------------------------------------------- */
 int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
               int64_t M, int N, int K, const float* bias, const float* img_bias,
-              int64_t rows_per_img, const void* residual, int64_t ldr, float out_scale,
-              unsigned flags, void* stream);
+              int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
+              float out_scale, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * mimo_conv2d: channels-last implicit-GEMM convolution (3x3 or 1x1), MFMA.
@@ -83,7 +84,7 @@ int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, i
  *   the virtual input is `in` itself, or its nearest-neighbour upsampling to
  *   [Hup, Wup] when Hup > 0 (src index = floor(dst * scale), scale = Hin/Hup as
  *   float, exactly torch's 'nearest').  Zero padding outside.
- *   epilogue: as mimo_gemm with rows_per_img = Hout*Wout.
+ *   epilogue: as mimo_gemm with rows_per_img = Hout*Wout*imgs_per_bias_row.
  * --------------------------------------------------------------------------------- */
 typedef struct mimo_conv_params {
   int n, Hin, Win, Cin;
@@ -93,6 +94,8 @@ typedef struct mimo_conv_params {
   int pad_t, pad_l;   /* zero padding before the first row / column */
   int Hup, Wup;       /* 0,0 = no upsampling; else virtual input size */
   int Cin2;           /* channels of in2 (0 = none) */
+  int imgs_per_bias_row; /* img_bias row = image / imgs_per_bias_row (frames of one batch element); 0 -> 1 */
+  int img_bias_ld;       /* row pitch of img_bias in floats; 0 -> Cout */
 } mimo_conv_params;
 
 int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,

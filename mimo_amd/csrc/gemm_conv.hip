@@ -29,7 +29,7 @@ struct GemmArgs {
   const float* bias;
   const float* img_bias;
   const void* res;
-  int64_t lda, ldw, ldo, ldr, M, rows_per_img;
+  int64_t lda, ldw, ldo, ldr, M, rows_per_img, ldib;
   int N, K;
   float out_scale;
   unsigned flags;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
       if (g.img_bias) {
-        const float4 b = *reinterpret_cast<const float4*>(g.img_bias + img * g.N + n);
+        const float4 b = *reinterpret_cast<const float4*>(g.img_bias + img * g.ldib + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
       int no = n;
@@ -279,18 +279,19 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
                          int64_t M, int N, int K, const float* bias, const float* img_bias,
-                         int64_t rows_per_img, const void* residual, int64_t ldr, float out_scale,
-                         unsigned flags, void* stream) {
+                         int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
+                         float out_scale, unsigned flags, void* stream) {
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return MIMO_EINVAL;
   if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out))
     return MIMO_EINVAL;
   if ((flags & MIMO_EPI_GEGLU) && (N & 31)) return MIMO_EINVAL;
   if (residual && (ldr & 3)) return MIMO_EINVAL;
-  if (img_bias && rows_per_img <= 0) return MIMO_EINVAL;
+  if (img_bias && (rows_per_img <= 0 || (img_bias_ld & 3))) return MIMO_EINVAL;
   GemmArgs g{};
   g.A = (const uint16_t*)A; g.A2 = nullptr; g.W = (const uint16_t*)W; g.out = out;
   g.bias = bias; g.img_bias = img_bias; g.res = residual;
   g.lda = lda; g.ldw = K; g.ldo = ldo; g.ldr = ldr; g.M = M; g.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
+  g.ldib = img_bias_ld > 0 ? img_bias_ld : N;
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
   g.nkt = (K + BK - 1) / BK;
   hipStream_t st = (hipStream_t)stream;
@@ -315,7 +316,9 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.N = p->Cout; g.K = p->ksize * p->ksize * p->Cin + p->Cin2;
   g.ldw = g.K; g.ldo = p->Cout; g.ldr = p->Cout; g.lda = 0;
   g.M = (int64_t)p->n * p->Hout * p->Wout;
-  g.rows_per_img = (int64_t)p->Hout * p->Wout;
+  g.rows_per_img = (int64_t)p->Hout * p->Wout * (p->imgs_per_bias_row > 0 ? p->imgs_per_bias_row : 1);
+  g.ldib = p->img_bias_ld > 0 ? p->img_bias_ld : p->Cout;
+  if (g.ldib & 3) return MIMO_EINVAL;
   g.out_scale = out_scale; g.flags = flags;
   g.Hin = p->Hin; g.Win = p->Win; g.Cin = p->Cin; g.Hout = p->Hout; g.Wout = p->Wout;
   g.ks = p->ksize; g.stride = p->stride; g.pad_t = p->pad_t; g.pad_l = p->pad_l;

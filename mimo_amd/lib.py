@@ -18,13 +18,14 @@ c_vp, c_i, c_i64, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctyp
 
 class ConvParams(ctypes.Structure):
     _fields_ = [(n, c_i) for n in ("n", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "ksize", "stride",
-                                   "pad_t", "pad_l", "Hup", "Wup", "Cin2")]
+                                   "pad_t", "pad_l", "Hup", "Wup", "Cin2", "imgs_per_bias_row",
+                                   "img_bias_ld")]
 
 
 # name -> argtypes, mirrors include/mimo_hip.h one to one
 SIGNATURES = {
     "mimo_version": [],
-    "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_f, c_u, c_vp],
+    "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp],
     "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],

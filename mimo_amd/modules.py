@@ -1,0 +1,366 @@
+"""Building blocks of the MI355X-native denoising path.
+
+Each class is (a) a parameter container whose attribute paths reproduce the reference's
+state-dict keys (so `denoising_unet.pth`, `reference_unet.pth`, `pose_guider.pth`,
+`motion_module.pth`, the SD1.5 unet and sd-vae-ft-mse checkpoints load unchanged) and (b) a
+`run()` method that executes the block with the HIP kernels of libmimo_hip.so through
+mimo_amd.ops.  nn.Conv2d / nn.Linear / nn.GroupNorm / nn.LayerNorm are used purely as parameter
+holders — their torch forward is never called; there is no torch compute fallback.
+
+Data layout: activations are channels-last token-major [n, H, W, C] with
+n = batch*frames images in frame-major order; the residual stream is fp32, every MFMA operand
+is fp16/bf16; the reference's `rearrange "b c f h w <-> (b f) c h w"` copies do not exist.
+
+Reference classes mirrored (paths relative to the reference repo):
+  ResnetBlock             src/models/resnet.py:123-247 (ResnetBlock3D) / diffusers ResnetBlock2D
+  Downsample, Upsample    src/models/resnet.py:31-120
+  SpatialTransformerBlock src/models/attention.py:298-445 + patched forward src/models/mutual_self_attention.py:93-276
+  SpatialTransformer      src/models/transformer_3d.py:27-169 (transformer_2d.py per image)
+  MotionModule            src/models/motion_module.py:44-390
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .packing import pack_conv, pack_geglu
+
+
+class Ctx:
+    """Per-forward execution context."""
+
+    def __init__(self, dtype, b, F):
+        self.dtype = dtype      # MFMA operand dtype (torch.float16 | torch.bfloat16)
+        self.b = b              # batch elements (CFG halves)
+        self.F = F              # frames per batch element (1 for 2-D models)
+        self.temb = None        # fp32 [b, sum(Cout)]: every ResBlock's time_emb_proj(silu(emb)) at once
+        self.attn2 = None       # fp32 [b, sum(C)]: every block's collapsed cross-attention output
+        self.stop_after = None  # write mode: block after whose bank write the rest of the graph is dead
+        self.bank_rows = None   # write mode: batch rows to bank (None = all)
+
+
+class EarlyExit(Exception):
+    pass
+
+
+class HipModule(nn.Module):
+    """Caches device-side packed weights per (dtype, device); invalidated by load_state_dict / _apply."""
+
+    def packed(self, dtype):
+        key = (dtype, self._dev())
+        cache = self.__dict__.setdefault("_pk", {})
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                cache[key] = self._pack(dtype)
+        return cache[key]
+
+    def _dev(self):
+        return next(self.parameters()).device
+
+    def invalidate(self):
+        for m in self.modules():
+            m.__dict__.pop("_pk", None)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate()
+        return super().load_state_dict(*a, **k)
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+class ResnetBlock(HipModule):
+    def __init__(self, in_channels, out_channels, temb_channels, groups=32, eps=1e-5, output_scale_factor=1.0):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels else None
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.groups, self.eps, self.output_scale_factor = groups, eps, output_scale_factor
+        self.temb_slice = None  # (start, end) columns of Ctx.temb, set by the owning UNet
+
+    def _pack(self, dt):
+        sc = self.conv_shortcut
+        b2 = _f32(self.conv2.bias)
+        if sc is not None:
+            b2 = b2 + _f32(sc.bias)
+        return dict(w1=pack_conv(self.conv1.weight, dt), b1=_f32(self.conv1.bias),
+                    w2=pack_conv(self.conv2.weight, dt, shortcut=None if sc is None else sc.weight), b2=b2,
+                    g1=_f32(self.norm1.weight), be1=_f32(self.norm1.bias),
+                    g2=_f32(self.norm2.weight), be2=_f32(self.norm2.bias))
+
+    def run(self, ctx, x, skip=None):
+        """x: fp32 [n,H,W,C1]; skip: fp32 [n,H,W,C2] concatenated virtually on the channel axis."""
+        p = self.packed(ctx.dtype)
+        fused_sc = self.conv_shortcut is not None
+        a1, raw = ops.group_norm(x, p["g1"], p["be1"], groups=self.groups, eps=self.eps, silu=True, x2=skip,
+                                 dtype=ctx.dtype, want_raw=fused_sc)
+        tb = None
+        if self.time_emb_proj is not None:
+            s, e = self.temb_slice
+            tb = ctx.temb[:, s:e]
+        h = ops.conv2d(a1, p["w1"], self.out_channels, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
+                       out_f32=True)
+        a2, _ = ops.group_norm(h, p["g2"], p["be2"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
+        return ops.conv2d(a2, p["w2"], self.out_channels, x2=raw, bias=p["b2"],
+                          residual=None if fused_sc else x, out_f32=True,
+                          out_scale=1.0 / self.output_scale_factor)
+
+
+class Downsample(HipModule):
+    """3x3 stride-2 conv; padding=1 (UNets) or diffusers' asymmetric (0,1,0,1) pad when padding=0 (VAE encoder)."""
+
+    def __init__(self, channels, out_channels=None, padding=1):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, stride=2, padding=padding)
+        self.padding = padding
+
+    def _pack(self, dt):
+        return dict(w=pack_conv(self.conv.weight, dt), b=_f32(self.conv.bias))
+
+    def run(self, ctx, x):
+        p = self.packed(ctx.dtype)
+        _, xh = ops.group_norm(x, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)  # cast only
+        n, H, W, _ = x.shape
+        if self.padding == 0:
+            return ops.conv2d(xh, p["w"], self.conv.out_channels, stride=2, pad=(0, 0),
+                              out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1), bias=p["b"], out_f32=True)
+        return ops.conv2d(xh, p["w"], self.conv.out_channels, stride=2, bias=p["b"], out_f32=True)
+
+
+class Upsample(HipModule):
+    """nearest x2 (or to an explicit size) folded into the 3x3 conv's gather."""
+
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, out_channels or channels, 3, padding=1)
+
+    def _pack(self, dt):
+        return dict(w=pack_conv(self.conv.weight, dt), b=_f32(self.conv.bias))
+
+    def run(self, ctx, x, output_size=None):
+        p = self.packed(ctx.dtype)
+        _, xh = ops.group_norm(x, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
+        n, H, W, _ = x.shape
+        size = (2 * H, 2 * W) if output_size is None else tuple(output_size)
+        return ops.conv2d(xh, p["w"], self.conv.out_channels, upsample_to=size, bias=p["b"], out_f32=True)
+
+
+class _Attn(nn.Module):
+    """Parameter holder with the diffusers Attention key layout (to_q/to_k/to_v/to_out.0)."""
+
+    def __init__(self, query_dim, cross_dim=None, heads=8, dim_head=64, bias=False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(cross_dim or query_dim, inner, bias=bias)
+        self.to_v = nn.Linear(cross_dim or query_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Identity()])
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, 2 * inner)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([_GEGLU(dim, 4 * dim), nn.Identity(), nn.Linear(4 * dim, dim)])
+
+
+def _ff_run(ctx, p, x_f32, norm_w, norm_b, out_f32):
+    """LN -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
+    n3 = ops.layer_norm(x_f32, norm_w, norm_b, dtype=ctx.dtype)
+    h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
+    return ops.gemm(h, p["ff2_w"], bias=p["ff2_b"], residual=x_f32, out_f32=out_f32)
+
+
+class SpatialTransformerBlock(HipModule):
+    """mode None: plain; 'write': bank norm1(x) (reference UNet); 'read': cond rows attend [self || bank]."""
+
+    def __init__(self, dim, heads, head_dim, cross_attention_dim):
+        super().__init__()
+        self.attn1 = _Attn(dim, None, heads, head_dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn2 = _Attn(dim, cross_attention_dim, heads, head_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.ff = _FeedForward(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.dim, self.heads = dim, heads
+        self.mode = None
+        self.bank = []        # write: [half [rows, N, C]]; read: same tensors handed over by update()
+        self.bank_kv = None   # read: half [Nb, 2C] = bank . [W_k ; W_v]^T, computed once per clip
+        self.attn2_slice = None
+
+    def _pack(self, dt):
+        a1 = self.attn1
+        ff1_w, ff1_b = pack_geglu(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, dt)
+        return dict(
+            qkv=torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
+            kv=torch.cat([a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
+            o_w=a1.to_out[0].weight.detach().to(dt).contiguous(), o_b=_f32(a1.to_out[0].bias),
+            ff1_w=ff1_w, ff1_b=ff1_b, ff2_w=self.ff.net[2].weight.detach().to(dt).contiguous(),
+            ff2_b=_f32(self.ff.net[2].bias),
+            n1w=_f32(self.norm1.weight), n1b=_f32(self.norm1.bias),
+            n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias))
+
+    def attn2_matrix(self):
+        """attn2 over ONE key collapses exactly: softmax == 1 -> out = to_out(to_v(e)) independent of the query
+        (src/models/attention.py:412-426 with encoder_hidden_states [b,1,768]).  Returns (W_o.W_v fp32 [C,768], b_o)."""
+        a2 = self.attn2
+        return a2.to_out[0].weight.detach().float() @ a2.to_v.weight.detach().float(), _f32(a2.to_out[0].bias)
+
+    def run(self, ctx, t, n_img, N, out_f32=False):
+        """t: fp32 tokens [n_img*N, C].  Returns the block output (half unless out_f32)."""
+        p = self.packed(ctx.dtype)
+        C = self.dim
+        n1 = ops.layer_norm(t, p["n1w"], p["n1b"], dtype=ctx.dtype)
+        if self.mode == "write":
+            bank = n1.view(n_img, N, C)
+            self.bank.append(bank if ctx.bank_rows is None else bank[ctx.bank_rows])
+            if ctx.stop_after is self:
+                raise EarlyExit()
+        qkv = ops.gemm(n1, p["qkv"]).view(n_img, N, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        if self.mode == "read" and self.bank_kv is not None:
+            # rows [0, F) of a CFG batch are unconditional: self-attention only (mutual_self_attention.py:179-197)
+            first = ctx.F if ctx.b == 2 else 0
+            o = ops.attention(q, k, v, self.heads, k2=self.bank_kv[:, :C], v2=self.bank_kv[:, C:],
+                              seg2_first_batch=first)
+        else:
+            o = ops.attention(q, k, v, self.heads)
+        s, e = self.attn2_slice
+        y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
+                     rows_per_img=ctx.F * N, residual=t, out_f32=True)
+        return _ff_run(ctx, p, y, p["n3w"], p["n3b"], out_f32)
+
+    def set_bank(self, bank, dtype):
+        """bank: half [1, Nb, C] (the cond reference features).  Projects K/V once (step- and frame-invariant)."""
+        p = self.packed(dtype)
+        self.bank = [bank]
+        self.bank_kv = ops.gemm(bank.reshape(-1, self.dim).to(dtype).contiguous(), p["kv"])
+
+
+class SpatialTransformer(HipModule):
+    def __init__(self, heads, head_dim, in_channels, cross_attention_dim, groups=32):
+        super().__init__()
+        inner = heads * head_dim
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([SpatialTransformerBlock(inner, heads, head_dim, cross_attention_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self.groups = groups
+
+    def _pack(self, dt):
+        C = self.proj_in.out_channels
+        return dict(g=_f32(self.norm.weight), b=_f32(self.norm.bias),
+                    pi_w=self.proj_in.weight.detach().reshape(C, -1).to(dt).contiguous(), pi_b=_f32(self.proj_in.bias),
+                    po_w=self.proj_out.weight.detach().reshape(self.proj_out.out_channels, -1).to(dt).contiguous(),
+                    po_b=_f32(self.proj_out.bias))
+
+    def run(self, ctx, x):
+        p = self.packed(ctx.dtype)
+        n, H, W, C = x.shape
+        g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=1e-6, silu=False, dtype=ctx.dtype)
+        t = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True)
+        z = self.transformer_blocks[0].run(ctx, t, n, H * W)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True)
+        return out.view(n, H, W, C)
+
+
+class _TemporalAttn(nn.Module):
+    def __init__(self, dim, heads, max_len):
+        super().__init__()
+        self.heads = heads
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(dim, dim, bias=False)
+        self.to_v = nn.Linear(dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+        self.pos_encoder = _PosEnc(dim, max_len)
+
+
+class _PosEnc(nn.Module):  # src/models/motion_module.py:264-279 (persistent buffer => a state-dict key)
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+
+class _TemporalBlock(nn.Module):
+    def __init__(self, dim, heads, max_len):
+        super().__init__()
+        self.attention_blocks = nn.ModuleList([_TemporalAttn(dim, heads, max_len) for _ in range(2)])
+        self.norms = nn.ModuleList([nn.LayerNorm(dim) for _ in range(2)])
+        self.ff = _FeedForward(dim)
+        self.ff_norm = nn.LayerNorm(dim)
+
+
+class _TemporalTransformer(nn.Module):
+    def __init__(self, in_channels, heads, max_len, groups=32):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = nn.Linear(in_channels, in_channels)
+        self.transformer_blocks = nn.ModuleList([_TemporalBlock(in_channels, heads, max_len)])
+        self.proj_out = nn.Linear(in_channels, in_channels)
+
+
+class MotionModule(HipModule):
+    """VanillaTemporalModule: GN -> Linear -> 2x{LN(+PE) -> attention over frames -> +res} -> LN -> GEGLU FF -> Linear -> +res."""
+
+    def __init__(self, in_channels, heads=8, max_len=32):
+        super().__init__()
+        self.temporal_transformer = _TemporalTransformer(in_channels, heads, max_len)
+        nn.init.zeros_(self.temporal_transformer.proj_out.weight)  # zero_module, motion_module.py:72-75
+        nn.init.zeros_(self.temporal_transformer.proj_out.bias)
+        self.dim, self.heads, self.max_len = in_channels, heads, max_len
+
+    def _pack(self, dt):
+        tt = self.temporal_transformer
+        blk = tt.transformer_blocks[0]
+        h = lambda w: w.detach().to(dt).contiguous()
+        ff1_w, ff1_b = pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, dt)
+        d = dict(g=_f32(tt.norm.weight), b=_f32(tt.norm.bias), pi_w=h(tt.proj_in.weight), pi_b=_f32(tt.proj_in.bias),
+                 po_w=h(tt.proj_out.weight), po_b=_f32(tt.proj_out.bias), ff1_w=ff1_w, ff1_b=ff1_b,
+                 ff2_w=h(blk.ff.net[2].weight), ff2_b=_f32(blk.ff.net[2].bias),
+                 fnw=_f32(blk.ff_norm.weight), fnb=_f32(blk.ff_norm.bias))
+        for i, (a, nrm) in enumerate(zip(blk.attention_blocks, blk.norms)):
+            d[f"qkv{i}"] = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous()
+            d[f"o_w{i}"], d[f"o_b{i}"] = h(a.to_out[0].weight), _f32(a.to_out[0].bias)
+            d[f"nw{i}"], d[f"nb{i}"] = _f32(nrm.weight), _f32(nrm.bias)
+            d[f"pe{i}"] = _f32(a.pos_encoder.pe[0])
+        return d
+
+    def run(self, ctx, x):
+        p = self.packed(ctx.dtype)
+        n, H, W, C = x.shape
+        HW = H * W
+        if ctx.F > self.max_len:
+            raise ValueError(f"window of {ctx.F} frames exceeds temporal_position_encoding_max_len={self.max_len}")
+        g, _ = ops.group_norm(x, p["g"], p["b"], groups=32, eps=1e-6, silu=False, dtype=ctx.dtype)
+        t = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True)
+        for i in range(2):
+            u = ops.layer_norm(t, p[f"nw{i}"], p[f"nb{i}"], dtype=ctx.dtype, pe=p[f"pe{i}"], rows_per_frame=HW,
+                               pe_frames=ctx.F)
+            qkv = ops.gemm(u, p[f"qkv{i}"])
+            o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
+            t = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True)
+        z = _ff_run(ctx, p, t, p["fnw"], p["fnb"], out_f32=False)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True)
+        return out.view(n, H, W, C)

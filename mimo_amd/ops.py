@@ -62,19 +62,24 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
         assert residual.dim() == 2 and residual.stride(1) == 1 and residual.shape[0] == M
         flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
         ldr = residual.stride(0)
+    ldib = 0
+    if img_bias is not None:
+        assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
+        ldib = img_bias.stride(0)
     L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
-           out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), rows_per_img, _ptr(residual), ldr,
+           out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
            float(out_scale), flags, _stream())
     return out
 
 
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
-           img_bias=None, residual=None, out_f32=False, silu=False, out_scale=1.0):
+           img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0):
     """Channels-last implicit-GEMM conv.  x: half [n, H, W, Cin]; w: packed half [cout, ks*ks*Cin (+Cin2)].
 
     pad = (pad_top, pad_left); default (ks//2, ks//2).  out_hw defaults to the torch formula for
     symmetric padding.  upsample_to = (Hup, Wup) applies nearest-neighbour upsampling first.
     x2: optional half [n, Hout, Wout, Cin2] fused as an extra 1x1 tap (ResBlock shortcut).
+    img_bias: fp32 [n / imgs_per_bias_row, cout] view (row-strided allowed): per-image additive vector.
     """
     _chk(x, "x")
     assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous()
@@ -91,7 +96,10 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
         cin2 = x2.shape[3]
     assert w.shape == (cout, ksize * ksize * cin + cin2), (w.shape, cout, ksize, cin, cin2)
     p = L.ConvParams(n, H, W, cin, Ho, Wo, cout, ksize, stride, pad[0], pad[1],
-                     Hv if upsample_to is not None else 0, Wv if upsample_to is not None else 0, cin2)
+                     Hv if upsample_to is not None else 0, Wv if upsample_to is not None else 0, cin2,
+                     imgs_per_bias_row, 0 if img_bias is None else img_bias.stride(0))
+    if img_bias is not None:
+        assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
     out = torch.empty((n, Ho, Wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     flags = (L.EPI_SILU if silu else 0) | (L.EPI_OUT_F32 if out_f32 else 0)
     if residual is not None:

@@ -1,0 +1,255 @@
+"""Pose2VideoPipeline on the MI355X-native models.
+
+Drop-in for src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py::Pose2VideoPipeline (constructor,
+`.to()`, `__call__` signature, `.videos` output) as called by run_animate.py:115-123,208-218 and
+run_edit.py:116-124,241-251.  `run_tensors()` is the device-resident core (what bench.py times):
+CLIP embedding + VAE encode (ref + F background frames) + pose guider + reference UNet (banks, once)
++ {sliding windows x CFG -> denoising UNet -> window average -> guidance -> DDIM} x steps + VAE decode.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): the independent work units of a step are
+(context window, CFG half) pairs; they are dealt round-robin to the ranks, each rank runs its units as
+b=1 denoising forwards, the per-unit predictions are exchanged with ONE all_gather per step and every rank
+replays the window sum in canonical order, so the result is bit-identical to the single-GPU run.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .context import get_context_scheduler
+from .unet import ReferenceAttentionControl
+
+VAE_SCALE = 0.18215  # hard-coded by the reference pipeline (:115,431,439)
+
+
+class Pose2VideoPipelineOutput:
+    def __init__(self, videos):
+        self.videos = videos
+
+
+def preprocess_image(image, height, width, normalize, scale_factor=8):
+    """diffusers VaeImageProcessor.preprocess as configured at pipeline :73-80: RGB, PIL LANCZOS resize to
+    (width, height) rounded down to a multiple of 8, /255, NCHW, optional 2x-1 (host-side, PIL)."""
+    from PIL import Image
+    image = image.convert("RGB")
+    w, h = width - width % scale_factor, height - height % scale_factor
+    image = image.resize((w, h), resample=Image.LANCZOS)
+    t = torch.from_numpy(np.array(image).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    return 2.0 * t - 1.0 if normalize else t
+
+
+def plan_units(num_windows, cfg, rank, world):
+    """Work decomposition of one denoising step.  Units = (window, half) in canonical order
+    (w0/uncond, w0/cond, w1/uncond, ...); unit u belongs to rank u % world.  Returns (all_units, my_units)."""
+    halves = (0, 1) if cfg else (0,)
+    units = [(w, h) for w in range(num_windows) for h in halves]
+    return units, [u for i, u in enumerate(units) if i % world == rank]
+
+
+def exchange_predictions(my_preds, units, rank, world, group=None):
+    """all_gather of the per-unit prediction tensors (equal shapes).  Returns {unit: tensor} for ALL units.
+    Ranks own ceil/floor(len(units)/world) units; short ranks pad with a zero tensor."""
+    import torch.distributed as dist
+    per_rank = math.ceil(len(units) / world)
+    proto = next(iter(my_preds.values())) if my_preds else None
+    if proto is None:  # a rank with no unit still needs the shape: broadcast it from rank 0's first unit
+        raise RuntimeError("every rank must own at least one unit (world size > number of units)")
+    mine = [u for i, u in enumerate(units) if i % world == rank]
+    send = torch.stack([my_preds[u] for u in mine] + [torch.zeros_like(proto)] * (per_rank - len(mine)))
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send.contiguous(), group=group)
+    out = {}
+    for i, u in enumerate(units):
+        out[u] = recv[i % world][i // world]
+    return out
+
+
+class Pose2VideoPipeline:
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
+                 image_proj_model=None, tokenizer=None, text_encoder=None):
+        self.vae, self.image_encoder = vae, image_encoder
+        self.reference_unet, self.denoising_unet, self.pose_guider = reference_unet, denoising_unet, pose_guider
+        self.scheduler = scheduler
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
+        self.dist_group = None
+        self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
+        self._clip_processor = None
+
+    def to(self, device=None, dtype=None):
+        for m in (self.vae, self.image_encoder, self.reference_unet, self.denoising_unet, self.pose_guider):
+            if isinstance(m, torch.nn.Module):
+                m.to(device=device, dtype=dtype)
+        return self
+
+    @property
+    def device(self):
+        return self.denoising_unet.device
+
+    def enable_vae_slicing(self):
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    # ------------------------------------------------------------------------------------------
+    def _encode_frames(self, images):
+        """images [n,3,H,W] in [-1,1] (device) -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
+        dt = self.vae.compute_dtype
+        outs = []
+        for i in range(0, images.shape[0], self.vae_batch):
+            tok = ops.ncfhw_to_tokens(images[i:i + self.vae_batch].contiguous()[:, :, None], dt, cpad=8)
+            outs.append(self.vae.encode_tokens(tok))
+        return torch.cat(outs) * VAE_SCALE
+
+    def _decode_frames(self, latents):
+        """latents fp32 [1,4,F,h,w] -> video fp32 [1,3,F,H,W] in [0,1] (decode_latents, pipeline :113-126)."""
+        dt = self.vae.compute_dtype
+        _, C, F, h, w = latents.shape
+        z = ops.ncfhw_to_tokens((latents * (1.0 / VAE_SCALE)).contiguous(), dt, cpad=8)  # [F,h,w,8]
+        frames = []
+        for i in range(0, F, self.vae_batch):
+            y = self.vae.decode_tokens(z[i:i + self.vae_batch].contiguous())
+            frames.append(ops.tokens_to_image(y, y.shape[0], y.shape[1], y.shape[2]))
+        return torch.cat(frames).permute(1, 0, 2, 3)[None]
+
+    @torch.no_grad()
+    def run_tensors(self, ref_image, bk_images, pose_images, clip_embeds, latents, num_inference_steps,
+                    guidance_scale, context_schedule="uniform", context_frames=24, context_stride=1,
+                    context_overlap=4, callback=None, return_latents=False, decode=True, trajectory=None):
+        """Device-resident core.  ref_image [1,3,H,W] in [-1,1]; bk_images [F,3,H,W] in [-1,1]; pose_images
+        [F,3,H,W] in [0,1]; clip_embeds [1,768]; latents fp32 [1,4,F,h,w] (the injected initial noise)."""
+        dev = self.device
+        unet, sched = self.denoising_unet, self.scheduler
+        dt = unet.compute_dtype
+        cfg = guidance_scale > 1.0
+        rank, world = 0, 1
+        if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
+            import torch.distributed as dist
+            rank, world = dist.get_rank(self.dist_group), dist.get_world_size(self.dist_group)
+        sched.set_timesteps(num_inference_steps)
+        latents = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
+        _, C, F, h, w = latents.shape
+
+        ehs_c = clip_embeds.to(dev).float().reshape(1, 1, -1)
+        ehs = torch.cat([torch.zeros_like(ehs_c), ehs_c], 0) if cfg else ehs_c
+
+        # VAE encode: reference image + F background frames; pose guider
+        ref_lat = self._encode_frames(ref_image.to(dev).float())               # [1,h,w,4]
+        bk_tok = self._encode_frames(bk_images.to(dev).float()).to(dt)         # [F,h,w,4]
+        pose_in = ops.ncfhw_to_tokens(pose_images.to(dev).float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
+        pose_tok = torch.cat([self.pose_guider.run_tokens(pose_in[i:i + self.vae_batch].contiguous())
+                              for i in range(0, F, self.vae_batch)])          # fp32 [F,h,w,C0]
+
+        # reference UNet at t = 0 (pipeline :480-490): only the cond element's banks are ever read, and
+        # everything after the last bank write is dead code -> run b = 1 with early exit.
+        writer = ReferenceAttentionControl(self.reference_unet, mode="write", do_classifier_free_guidance=cfg)
+        reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=cfg)
+        ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=self.reference_unet.compute_dtype)
+        ref_tok[..., :C] = ref_lat.to(ref_tok.dtype)
+        from .modules import Ctx, EarlyExit
+        rctx = Ctx(self.reference_unet.compute_dtype, 1, 1)
+        rctx.stop_after = writer.last_block()
+        try:
+            self.reference_unet.run_tokens(ref_tok, 0, ehs_c, 1, 1, None, rctx)
+        except EarlyExit:
+            pass
+        reader.update(writer)
+
+        windows = get_context_scheduler(context_schedule)(0, num_inference_steps, F, context_frames, context_stride,
+                                                          context_overlap)
+        win_idx = [torch.tensor(c, dtype=torch.int32, device=dev) for c in windows]
+        win_bk = [bk_tok[c.long()] for c in win_idx]
+        win_pose = [pose_tok[c.long()] for c in win_idx]
+        units, my_units = plan_units(len(windows), cfg, rank, world)
+        acc = torch.empty((2 if cfg else 1, C, F, h, w), device=dev, dtype=torch.float32)
+        counter = torch.empty((F,), device=dev, dtype=torch.float32)
+
+        for step, t in enumerate(sched.timesteps.tolist()):
+            acc.zero_()
+            counter.zero_()
+            preds = {}
+            if world == 1:
+                for wi, idx in enumerate(win_idx):
+                    lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)                   # [Fw,h,w,4]
+                    x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
+                    rep = 2 if cfg else 1
+                    pred = unet.run_tokens(x.repeat(rep, 1, 1, 1), t, ehs, rep, idx.numel(),
+                                           win_pose[wi].repeat(rep, 1, 1, 1))
+                    ops.window_accumulate(pred, idx, acc, counter)
+            else:
+                for (wi, half) in my_units:
+                    idx = win_idx[wi]
+                    lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
+                    x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
+                    e = ehs[half:half + 1] if cfg else ehs
+                    preds[(wi, half)] = self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg))
+                allp = exchange_predictions(preds, units, rank, world, self.dist_group)
+                for wi, idx in enumerate(win_idx):
+                    halves = [allp[(wi, hf)] for hf in ((0, 1) if cfg else (0,))]
+                    ops.window_accumulate(torch.cat(halves, 0).contiguous(), idx, acc, counter)
+            ops.cfg_ddim_step(acc, counter, latents, cfg, guidance_scale, *sched.coefficients(t))
+            if trajectory is not None:
+                trajectory.append(latents.clone())
+            if callback is not None:
+                callback(step, t, latents)
+        reader.clear()
+        writer.clear()
+        if not decode:
+            return latents
+        video = self._decode_frames(latents)
+        return (video, latents) if return_latents else video
+
+    def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond):
+        """One (window, CFG half) unit as a b = 1 forward.  The uncond half must not read the bank."""
+        blocks = unet.spatial_blocks()
+        saved = None
+        if not cond:
+            saved = [b.bank_kv for b in blocks]
+            for b in blocks:
+                b.bank_kv = None
+        try:
+            return unet.run_tokens(x, t, ehs1, 1, Fw, pose)
+        finally:
+            if saved is not None:
+                for b, kv in zip(blocks, saved):
+                    b.bank_kv = kv
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, ref_image, pose_images, vid_bk_images, width, height, video_length, num_inference_steps,
+                 guidance_scale, num_images_per_prompt=1, eta=0.0, generator=None, output_type="tensor",
+                 return_dict=True, callback=None, callback_steps=1, context_schedule="uniform", context_frames=24,
+                 context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
+        if eta != 0.0 or context_batch_size != 1 or interpolation_factor != 1:
+            raise NotImplementedError("eta=0, context_batch_size=1, interpolation_factor=1 (the reference defaults) only")
+        dev = self.device
+        # CLIP image embedding (pipeline :379-384).  The image encoder is outside the accelerated path
+        # (SURVEY.md §8f rank 1): any module returning `.image_embeds` works (transformers CLIPVisionModelWithProjection).
+        if self._clip_processor is None:
+            from transformers import CLIPImageProcessor
+            self._clip_processor = CLIPImageProcessor()
+        clip_image = self._clip_processor.preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        enc_dtype = getattr(self.image_encoder, "dtype", torch.float32)
+        clip_embeds = self.image_encoder(clip_image.to(dev, dtype=enc_dtype)).image_embeds
+        h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        # prepare_latents (:149-183): CPU generator draws on CPU in the embedding dtype, then moves
+        shape = (1, 4, video_length, h, w)
+        gdev = generator.device.type if generator is not None else "cpu"
+        if gdev == "cpu":
+            latents = torch.randn(shape, generator=generator, device="cpu", dtype=clip_embeds.dtype).to(dev)
+        else:
+            latents = torch.randn(shape, generator=generator, device=dev, dtype=clip_embeds.dtype)
+        ref_t = preprocess_image(ref_image, height, width, True)
+        bk_t = torch.cat([preprocess_image(im, height, width, True) for im in vid_bk_images])
+        pose_t = torch.cat([preprocess_image(im, height, width, False) for im in pose_images])
+        cb = None
+        if callback is not None:
+            cb = lambda i, t, lat: callback(i, t, lat) if i % callback_steps == 0 else None
+        video = self.run_tensors(ref_t, bk_t, pose_t, clip_embeds, latents.float(), num_inference_steps, guidance_scale,
+                                 context_schedule, context_frames, context_stride, context_overlap, callback=cb)
+        images = video.cpu().float()
+        if output_type != "tensor":
+            images = images.numpy()
+        return Pose2VideoPipelineOutput(videos=images) if return_dict else images

@@ -1,0 +1,318 @@
+"""sd-vae-ft-mse encode/decode and the pose guider on the HIP kernels.
+
+  AutoencoderKL  drop-in for diffusers.AutoencoderKL as used by the reference
+                 (run_animate.py:70-72; src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py:71,120,430,438):
+                 .encode(x).latent_dist.mean, .decode(z).sample, .config.block_out_channels, state-dict keys
+                 of the diffusers checkpoint (new and deprecated attention key names accepted).
+  PoseGuider     drop-in for src/models/pose_guider.py.
+
+The reference encodes/decodes one frame per Python-loop iteration; here all frames go through each layer
+as one batch (GroupNorm statistics are per image, so the arithmetic per frame is unchanged).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32
+from .packing import pack_conv, pad_vec
+
+
+class _VaeAttn(nn.Module):
+    def __init__(self, ch, groups, eps):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, ch, eps=eps)
+        self.to_q = nn.Linear(ch, ch)
+        self.to_k = nn.Linear(ch, ch)
+        self.to_v = nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
+
+
+class VaeMidBlock(HipModule):
+    """resnet -> single-head attention (d = C, GN eps 1e-6, residual) -> resnet  (diffusers UNetMidBlock2D)."""
+
+    def __init__(self, ch, groups, eps):
+        super().__init__()
+        self.attentions = nn.ModuleList([_VaeAttn(ch, groups, eps)])
+        self.resnets = nn.ModuleList([ResnetBlock(ch, ch, None, groups, eps), ResnetBlock(ch, ch, None, groups, eps)])
+        self.ch, self.groups, self.eps = ch, groups, eps
+
+    def _pack(self, dt):
+        a = self.attentions[0]
+        return dict(g=_f32(a.group_norm.weight), b=_f32(a.group_norm.bias),
+                    qkv_w=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous(),
+                    qkv_b=torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], 0).detach().float().contiguous(),
+                    o_w=a.to_out[0].weight.detach().to(dt).contiguous(), o_b=_f32(a.to_out[0].bias))
+
+    def run(self, ctx, x):
+        p = self.packed(ctx.dtype)
+        x = self.resnets[0].run(ctx, x)
+        n, H, W, C = x.shape
+        N = H * W
+        if N % 8:
+            raise NotImplementedError("VAE mid-block attention needs H*W/64 to be a multiple of 8 tokens")
+        g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=False, dtype=ctx.dtype)
+        qkv = ops.gemm(g.view(-1, C), p["qkv_w"], bias=p["qkv_b"]).view(n, N, 3 * C)
+        o = torch.empty((n, N, C), device=x.device, dtype=ctx.dtype)
+        for i in range(n):  # d = 512 single head: scores / softmax / P.V as GEMM + row-softmax + GEMM
+            q, k, v = qkv[i, :, :C], qkv[i, :, C:2 * C], qkv[i, :, 2 * C:]
+            s = ops.gemm(q, k.contiguous(), out_f32=True)
+            pr = ops.softmax_rows(s, ctx.dtype, scale=C ** -0.5)
+            ops.gemm(pr, v.t().contiguous(), out=o[i])
+        y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], residual=x.view(-1, C), out_f32=True).view(n, H, W, C)
+        return self.resnets[1].run(ctx, y)
+
+
+class _EncDownBlock(nn.Module):
+    def __init__(self, cin, cout, layers, add_down, groups, eps):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock(cin if i == 0 else cout, cout, None, groups, eps) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample(cout, cout, padding=0)]) if add_down else None
+
+    def run(self, ctx, x):
+        for r in self.resnets:
+            x = r.run(ctx, x)
+        return x if self.downsamplers is None else self.downsamplers[0].run(ctx, x)
+
+
+class _DecUpBlock(nn.Module):
+    def __init__(self, cin, cout, layers, add_up, groups, eps):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock(cin if i == 0 else cout, cout, None, groups, eps) for i in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample(cout, cout)]) if add_up else None
+
+    def run(self, ctx, x):
+        for r in self.resnets:
+            x = r.run(ctx, x)
+        return x if self.upsamplers is None else self.upsamplers[0].run(ctx, x)
+
+
+class Encoder(HipModule):
+    def __init__(self, in_channels, out_channels, boc, layers, groups, eps=1e-6):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        c = boc[0]
+        for i, co in enumerate(boc):
+            self.down_blocks.append(_EncDownBlock(c, co, layers, i != len(boc) - 1, groups, eps))
+            c = co
+        self.mid_block = VaeMidBlock(c, groups, eps)
+        self.conv_norm_out = nn.GroupNorm(groups, c, eps=eps)
+        self.conv_out = nn.Conv2d(c, 2 * out_channels, 3, padding=1)
+        self.groups, self.eps = groups, eps
+
+    def _pack(self, dt):
+        return dict(ci_w=pack_conv(self.conv_in.weight, dt, cin_pad=8), ci_b=_f32(self.conv_in.bias),
+                    g=_f32(self.conv_norm_out.weight), b=_f32(self.conv_norm_out.bias),
+                    co_w=pack_conv(self.conv_out.weight, dt), co_b=_f32(self.conv_out.bias))
+
+    def run(self, ctx, x_tok):
+        p = self.packed(ctx.dtype)
+        x = ops.conv2d(x_tok, p["ci_w"], self.conv_in.out_channels, bias=p["ci_b"], out_f32=True)
+        for blk in self.down_blocks:
+            x = blk.run(ctx, x)
+        x = self.mid_block.run(ctx, x)
+        a, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
+        return ops.conv2d(a, p["co_w"], self.conv_out.out_channels, bias=p["co_b"])  # half: feeds quant_conv
+
+
+class Decoder(HipModule):
+    def __init__(self, in_channels, out_channels, boc, layers, groups, eps=1e-6):
+        super().__init__()
+        rev = list(reversed(boc))
+        self.conv_in = nn.Conv2d(in_channels, rev[0], 3, padding=1)
+        self.mid_block = VaeMidBlock(rev[0], groups, eps)
+        self.up_blocks = nn.ModuleList()
+        c = rev[0]
+        for i, co in enumerate(rev):
+            self.up_blocks.append(_DecUpBlock(c, co, layers + 1, i != len(rev) - 1, groups, eps))
+            c = co
+        self.conv_norm_out = nn.GroupNorm(groups, c, eps=eps)
+        self.conv_out = nn.Conv2d(c, out_channels, 3, padding=1)
+        self.groups, self.eps = groups, eps
+
+    def _pack(self, dt):
+        return dict(ci_w=pack_conv(self.conv_in.weight, dt, cin_pad=8), ci_b=_f32(self.conv_in.bias),
+                    g=_f32(self.conv_norm_out.weight), b=_f32(self.conv_norm_out.bias),
+                    co_w=pack_conv(self.conv_out.weight, dt, cout_pad=4), co_b=pad_vec(self.conv_out.bias, 4))
+
+    def run(self, ctx, z_tok):
+        p = self.packed(ctx.dtype)
+        x = ops.conv2d(z_tok, p["ci_w"], self.conv_in.out_channels, bias=p["ci_b"], out_f32=True)
+        x = self.mid_block.run(ctx, x)
+        for blk in self.up_blocks:
+            x = blk.run(ctx, x)
+        a, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
+        return ops.conv2d(a, p["co_w"], 4, bias=p["co_b"], out_f32=True)  # [n,H,W,4], channel 3 is padding
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class _Dist:
+    def __init__(self, mean):
+        self.mean = mean
+
+    def mode(self):
+        return self.mean
+
+
+class _Out:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+_DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+class AutoencoderKL(HipModule):
+    def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 latent_channels=4, norm_num_groups=32, act_fn="silu", sample_size=256, scaling_factor=0.18215, **unused):
+        super().__init__()
+        boc = list(block_out_channels)
+        self.config = _Cfg(in_channels=in_channels, out_channels=out_channels, block_out_channels=boc,
+                           layers_per_block=layers_per_block, latent_channels=latent_channels,
+                           norm_num_groups=norm_num_groups, scaling_factor=scaling_factor)
+        self.encoder = Encoder(in_channels, latent_channels, boc, layers_per_block, norm_num_groups)
+        self.decoder = Decoder(latent_channels, out_channels, boc, layers_per_block, norm_num_groups)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+        self.compute_dtype = torch.float16
+        self.latent_channels = latent_channels
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    def enable_slicing(self):  # the batched path already streams frames through each layer
+        pass
+
+    def disable_slicing(self):
+        pass
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if self.quant_conv.weight.dtype in (torch.float16, torch.bfloat16):
+            self.compute_dtype = self.quant_conv.weight.dtype
+        return r
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        fixed = {}
+        for k, v in sd.items():
+            parts = k.split(".")
+            if "attentions" in parts:
+                for old, new in _DEPRECATED_ATTN.items():
+                    if parts[-2] == old:
+                        k = ".".join(parts[:-2] + [new, parts[-1]])
+                        if v.dim() == 4:
+                            v = v.reshape(v.shape[0], v.shape[1])
+            fixed[k] = v
+        return super().load_state_dict(fixed, strict=strict, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path, **kw):
+        import json
+        from pathlib import Path
+        from .unet import _load_weights
+        path = Path(path)
+        model = cls(**json.loads((path / "config.json").read_text()))
+        model.load_state_dict(_load_weights(path))
+        return model
+
+    def _pack(self, dt):
+        lc = self.latent_channels
+        # quant_conv: only the mean half is consumed (latent_dist.mean); pad 4 -> 8 input ch of post_quant_conv
+        return dict(q_w=self.quant_conv.weight.detach().reshape(2 * lc, 2 * lc)[:lc].to(dt).contiguous(),
+                    q_b=_f32(self.quant_conv.bias)[:lc].contiguous(),
+                    pq_w=torch.nn.functional.pad(self.post_quant_conv.weight.detach().float().reshape(lc, lc),
+                                                 (0, 8 - lc, 0, 8 - lc)).to(dt).contiguous(),  # [8,8], zero pad rows/cols
+                    pq_b=pad_vec(self.post_quant_conv.bias, 8))
+
+    # ---- token-level API used by the pipeline ----
+    def encode_tokens(self, x_tok):
+        """x_tok: half [n,H,W,8] (RGB in [-1,1] + 5 zero channels) -> posterior mean, fp32 tokens [n,H/8,W/8,4]."""
+        dt = self.compute_dtype
+        ctx = Ctx(dt, x_tok.shape[0], 1)
+        p = self.packed(dt)
+        h = self.encoder.run(ctx, x_tok)
+        n, hh, ww, c = h.shape
+        return ops.gemm(h.view(-1, c), p["q_w"], bias=p["q_b"], out_f32=True).view(n, hh, ww, self.latent_channels)
+
+    def decode_tokens(self, z_tok):
+        """z_tok: half [n,h,w,8] (4 latent channels + 4 zero) -> fp32 tokens [n,8h,8w,4] (RGB + 1 pad channel)."""
+        dt = self.compute_dtype
+        ctx = Ctx(dt, z_tok.shape[0], 1)
+        p = self.packed(dt)
+        n, h, w, c = z_tok.shape
+        z8 = ops.gemm(z_tok.view(-1, c), p["pq_w"], bias=p["pq_b"]).view(n, h, w, 8)  # channels 4..7 stay zero
+        return self.decoder.run(ctx, z8)
+
+    # ---- diffusers-compatible surface ----
+    def encode(self, x, return_dict=True):
+        """x: [n,3,H,W] in [-1,1] -> .latent_dist.mean [n,4,H/8,W/8]"""
+        tok = ops.ncfhw_to_tokens(x.contiguous()[:, :, None], self.compute_dtype, cpad=8)
+        m = self.encode_tokens(tok)
+        return _Out(latent_dist=_Dist(m.permute(0, 3, 1, 2).contiguous().to(x.dtype)))
+
+    def decode(self, z, return_dict=True):
+        """z: [n,4,h,w] -> .sample [n,3,8h,8w]"""
+        tok = ops.ncfhw_to_tokens(z.contiguous()[:, :, None], self.compute_dtype, cpad=8)
+        y = self.decode_tokens(tok)
+        return _Out(sample=y[..., :3].permute(0, 3, 1, 2).contiguous().to(z.dtype))
+
+
+class PoseGuider(HipModule):
+    """conv 3->16, {16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2}, 256->C; SiLU between (pose_guider.py:47-57)."""
+
+    def __init__(self, conditioning_embedding_channels=320, conditioning_channels=3, block_out_channels=(16, 32, 96, 256)):
+        super().__init__()
+        boc = block_out_channels
+        self.conv_in = nn.Conv2d(conditioning_channels, boc[0], 3, padding=1)
+        self.blocks = nn.ModuleList()
+        for i in range(len(boc) - 1):
+            self.blocks.append(nn.Conv2d(boc[i], boc[i], 3, padding=1))
+            self.blocks.append(nn.Conv2d(boc[i], boc[i + 1], 3, padding=1, stride=2))
+        self.conv_out = nn.Conv2d(boc[-1], conditioning_embedding_channels, 3, padding=1)
+        nn.init.zeros_(self.conv_out.weight)  # zero_module (pose_guider.py:38-45)
+        nn.init.zeros_(self.conv_out.bias)
+        self.compute_dtype = torch.float16
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        if self.conv_in.weight.dtype in (torch.float16, torch.bfloat16):
+            self.compute_dtype = self.conv_in.weight.dtype
+        return r
+
+    def _pack(self, dt):
+        convs = [self.conv_in] + list(self.blocks) + [self.conv_out]
+        return dict(w=[pack_conv(c.weight, dt, cin_pad=8 if i == 0 else None) for i, c in enumerate(convs)],
+                    b=[_f32(c.bias) for c in convs])
+
+    def run_tokens(self, x_tok):
+        """x_tok: half [F,H,W,8] (RGB in [0,1] + zero pad) -> fp32 tokens [F,H/8,W/8,C]."""
+        p = self.packed(self.compute_dtype)
+        convs = [self.conv_in] + list(self.blocks) + [self.conv_out]
+        x = x_tok
+        for i, c in enumerate(convs):
+            last = i == len(convs) - 1
+            x = ops.conv2d(x, p["w"][i], c.out_channels, stride=c.stride[0], bias=p["b"][i], silu=not last, out_f32=last)
+        return x
+
+    def forward(self, conditioning):
+        """[1,3,F,H,W] -> [1,C,F,H/8,W/8] like the reference."""
+        b, c, f, H, W = conditioning.shape
+        tok = ops.ncfhw_to_tokens(conditioning.contiguous(), self.compute_dtype, cpad=8)
+        y = self.run_tokens(tok)
+        return ops.tokens_to_ncfhw(y, b, y.shape[-1], f, y.shape[1], y.shape[2]).to(conditioning.dtype)

@@ -1,0 +1,215 @@
+"""Block- and model-level parity on the GPU: product (HIP kernels through the C-ABI) vs the CPU fp32 oracle on
+identical seeded weights and inputs.  Metric: relative L2 of the output.  Policy under test: fp16/bf16
+only as MFMA inputs, fp32 accumulation / statistics / softmax / residual stream."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import MM4, build_pair_pose, build_pair_unets, build_pair_vae, small_kw
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+# single-module tolerances; whole-model numbers are logged and asserted separately below
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def to_tok(x5):  # [b,c,f,h,w] -> [b*f,h,w,c]
+    b, c, f, h, w = x5.shape
+    return x5.permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c).contiguous()
+
+
+def from_tok(t, b, f):  # [b*f,h,w,c] -> [b,c,f,h,w]
+    n, h, w, c = t.shape
+    return t.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cskip,cout", [(320, 0, 320), (320, 0, 640), (640, 320, 320), (1280, 640, 640)])
+def test_resnet_block(dev, dtype, cin, cskip, cout):
+    from mimo_amd.modules import Ctx, ResnetBlock
+    from oracle import models as OM, synth
+    b, F, h = 2, 3, 8
+    o = synth.build(OM.ResnetBlock3D, 3, in_channels=cin + cskip, out_channels=cout, temb_channels=1280)
+    p = ResnetBlock(cin + cskip, cout, 1280)
+    p.load_state_dict(o.state_dict(), strict=True)
+    p.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, cin, F, h, h, generator=g)
+    skip = torch.randn(b, cskip, F, h, h, generator=g) if cskip else None
+    temb = torch.randn(b, 1280, generator=g)
+    ref = o(torch.cat([x, skip], 1) if cskip else x, temb)
+    ctx = Ctx(dtype, b, F)
+    ctx.temb = (torch.nn.functional.silu(temb) @ o.time_emb_proj.weight.t() + o.time_emb_proj.bias).to(dev).contiguous()
+    p.temb_slice = (0, cout)
+    out = p.run(ctx, to_tok(x).to(dev), None if skip is None else to_tok(skip).to(dev))
+    e = rel_l2(from_tok(out.cpu(), b, F), ref)
+    report(f"resnet {cin}+{cskip}->{cout} {dtype}: rel_l2={e:.2e}")
+    assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,heads,hw", [(320, 8, 8), (640, 8, 6), (1280, 8, 4)])
+def test_spatial_transformer_read_mode(dev, dtype, C, heads, hw):
+    """cond rows attend [self || bank], uncond rows self only, 1-key cross-attention collapsed to a bias."""
+    from mimo_amd.modules import Ctx, SpatialTransformer
+    from oracle import models as OM, synth
+    b, F = 2, 3
+    o = synth.build(OM.Transformer3DModel, 5, heads=heads, head_dim=C // heads, in_channels=C, cross_attention_dim=768)
+    p = SpatialTransformer(heads, C // heads, C, 768)
+    p.load_state_dict(o.state_dict(), strict=True)
+    p.to(dev)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(b, C, F, hw, hw, generator=g)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)])
+    bank = torch.randn(2, hw * hw, C, generator=g).to(torch.float16)  # reference casts banks to fp16
+    ob = o.transformer_blocks[0]
+    ob.mode, ob.bank, ob.do_cfg = "read", [bank], True
+    ref = o(x, ehs)
+    pb = p.transformer_blocks[0]
+    pb.mode = "read"
+    pb.attn2_slice = (0, C)
+    pb.set_bank(bank[1:].to(dev), dtype)
+    ctx = Ctx(dtype, b, F)
+    w, bias = pb.attn2_matrix()
+    ctx.attn2 = (ehs[:, 0].to(dev) @ w.t() + bias).contiguous()
+    out = p.run(ctx, to_tok(x).to(dev))
+    e = rel_l2(from_tok(out.cpu(), b, F), ref)
+    report(f"spatial transformer C{C} {dtype}: rel_l2={e:.2e}")
+    assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,F,hw", [(320, 24, 4), (640, 8, 5), (1280, 24, 2)])
+def test_motion_module(dev, dtype, C, F, hw):
+    from mimo_amd.modules import Ctx, MotionModule
+    from oracle import models as OM, synth
+    b = 2
+    o = synth.build(OM.VanillaTemporalModule, 7, in_channels=C)
+    p = MotionModule(C)
+    p.load_state_dict(o.state_dict(), strict=True)
+    p.to(dev)
+    x = torch.randn(b, C, F, hw, hw, generator=torch.Generator().manual_seed(3))
+    ref = o(x)
+    out = p.run(Ctx(dtype, b, F), to_tok(x).to(dev))
+    e = rel_l2(from_tok(out.cpu(), b, F) - x, ref - x)  # compare the module's residual branch, not the identity
+    report(f"motion module C{C} F{F} {dtype}: rel_l2(branch)={e:.2e}")
+    assert e < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pose_guider(dev, dtype):
+    og, pg = build_pair_pose(dtype, dev)
+    x = torch.rand(1, 3, 3, 32, 40, generator=torch.Generator().manual_seed(4))
+    ref = og(x)
+    out = pg(x.to(dev)).cpu()
+    e = rel_l2(out, ref)
+    report(f"pose guider {dtype}: rel_l2={e:.2e}")
+    assert e < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vae_encode_decode(dev, dtype):
+    ov, pv = build_pair_vae(dtype, dev)
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    ref_m = ov.encode(img).latent_dist.mean
+    out_m = pv.encode(img.to(dev)).latent_dist.mean.cpu()
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    ref_d = ov.decode(z).sample
+    out_d = pv.decode(z.to(dev)).sample.cpu()
+    e1, e2 = rel_l2(out_m, ref_m), rel_l2(out_d, ref_d)
+    report(f"vae {dtype}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
+    assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
+
+
+def _run_oracle_unet(o3, o2, x, t, ehs, pose, ref_lat):
+    from oracle import models as OM
+    w = OM.ReferenceAttentionControl(o2, "write")
+    r = OM.ReferenceAttentionControl(o3, "read")
+    o2(ref_lat.repeat(2, 1, 1, 1), torch.zeros(()), ehs)
+    r.update(w)
+    out = o3(x, t, ehs, pose_cond_fea=pose)
+    banks = [b.bank[0].clone() for b in o3.spatial_blocks()]
+    r.clear()
+    w.clear()
+    return out, banks
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw,F", [(16, 8), (13, 3)])
+def test_denoising_unet_forward_with_reference_bank(dev, dtype, hw, F):
+    """Whole denoising-UNet forward (read mode, CFG batch) + reference-UNet bank capture vs the oracle,
+    through the reference-compatible forward() surfaces."""
+    from mimo_amd.unet import ReferenceAttentionControl
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev)
+    g = torch.Generator().manual_seed(6)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)])
+    ref_lat = torch.randn(1, 4, hw, hw, generator=g)
+    x = torch.randn(2, 8, F, hw, hw, generator=g)
+    pose = torch.randn(2, 160, F, hw, hw, generator=g)
+    t = 749
+    with torch.no_grad():
+        ref, banks = _run_oracle_unet(o3, o2, x, torch.tensor(t), ehs, pose, ref_lat)
+    w = ReferenceAttentionControl(p2, mode="write", do_classifier_free_guidance=True)
+    r = ReferenceAttentionControl(p3, mode="read", do_classifier_free_guidance=True)
+    p2(ref_lat.repeat(2, 1, 1, 1).to(dev), 0, ehs.to(dev), stop_after=w.last_block())
+    r.update(w)
+    for ob, pb in zip(banks, p3.spatial_blocks()):  # bank parity (cond row), incl. pairing order
+        assert rel_l2(pb.bank[0][0].float().cpu(), ob[1].float()) < TOL[dtype]
+    out = p3(x.to(dev), t, ehs.to(dev), pose_cond_fea=pose.to(dev), return_dict=False)[0].cpu()
+    e = rel_l2(out, ref)
+    e_u, e_c = rel_l2(out[0], ref[0]), rel_l2(out[1], ref[1])
+    report(f"denoising unet fwd hw{hw} F{F} {dtype}: rel_l2={e:.2e} (uncond {e_u:.2e}, cond {e_c:.2e})")
+    assert e < {torch.float16: 3e-3, torch.bfloat16: 3e-2}[dtype]
+    # the uncond half must not depend on the bank (mutual_self_attention.py:189-197)
+    for blk in p3.spatial_blocks():
+        blk.bank_kv = None
+    out2 = p3(x.to(dev), t, ehs.to(dev), pose_cond_fea=pose.to(dev), return_dict=False)[0].cpu()
+    assert torch.equal(out2[0], out[0]) and not torch.equal(out2[1], out[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
+    """run_tensors (VAE encode, pose guider, reference UNet, 2 DDIM steps x 2 wrapped windows x CFG, VAE decode)
+    vs oracle.pipeline.run_clip on identical injected latents: final latents and decoded video."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=61)
+    ov, pv = build_pair_vae(dtype, dev, seed=62)
+    og, pg = build_pair_pose(dtype, dev, seed=63)
+    H = W = 64
+    F = 26
+    g = torch.Generator().manual_seed(7)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        vid_o, lat_o = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), clip, ref_img, bk, pose,
+                                lat, 2, 3.5)
+    pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    vid_p, lat_p = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, 3.5,
+                                    return_latents=True)
+    e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
+    report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
+    assert vid_p.shape == (1, 3, F, H, W)
+    assert e_lat < {torch.float16: 3e-3, torch.bfloat16: 3e-2}[dtype]

@@ -138,6 +138,11 @@ def test_conv2d_resblock_epilogue_and_fused_shortcut(dev, dtype):
     out = ops.conv2d(h, pack_conv(w, dtype, shortcut=ws), cout, x2=x, bias=b, img_bias=temb, residual=res,
                      out_f32=True)
     assert rel_l2(out, ref) < ACC_TOL
+    # img_bias as a column slice of a wider matrix, one row per group of 3 images (batch element)
+    wide = rnd((1, 3 * cout), dev, torch.float32, 8)
+    out2 = ops.conv2d(h, pack_conv(w, dtype, shortcut=ws), cout, x2=x, bias=b, img_bias=wide[:, cout:2 * cout],
+                      imgs_per_bias_row=3, residual=res, out_f32=True)
+    assert rel_l2(out2, ref - temb[:, None, None, :] + wide[:, None, None, cout:2 * cout]) < ACC_TOL
     out = ops.conv2d(h, pack_conv(w, dtype), cout, bias=b, silu=True)
     assert rel_l2(out.float(), F.silu(torch_conv_ref(h, w, b, 3, 1, None, None, None))) < OUT_TOL[dtype]
 
