@@ -13,6 +13,16 @@ from . import lib as L
 
 _DT = {torch.float16: L.F16, torch.bfloat16: L.BF16}
 
+# Optional accounting of the algorithmic FLOPs actually launched (2*MACs of every GEMM / conv / attention
+# product); bench.py sets COUNTER = {"flops": 0, "launches": 0} around a forward to price the roofline.
+COUNTER = None
+
+
+def _count(flops):
+    if COUNTER is not None:
+        COUNTER["flops"] += flops
+        COUNTER["launches"] += 1
+
 
 def dt_code(dtype):
     try:
@@ -66,6 +76,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     if img_bias is not None:
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
         ldib = img_bias.stride(0)
+    _count(2 * M * N * K)
     L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
            out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
            float(out_scale), flags, _stream())
@@ -105,6 +116,7 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == out.shape
         flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
+    _count(2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2))
     L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
            ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags, _stream())
     return out
@@ -172,6 +184,7 @@ def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=Non
     out = torch.empty((B, Nq, C), device=q.device, dtype=q.dtype)
     if scale is None:
         scale = d ** -0.5
+    _count(4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2))
     L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
            v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
            seg2_first_batch, heads, d, float(scale), _stream())
@@ -187,6 +200,7 @@ def temporal_attention(q, k, v, b, F, HW, heads, *, scale=None):
     out = torch.empty((q.shape[0], C), device=q.device, dtype=q.dtype)
     if scale is None:
         scale = d ** -0.5
+    _count(4 * b * HW * F * F * C)
     L.call("mimo_temporal_attention", dt_code(q.dtype), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0),
            v.data_ptr(), v.stride(0), out.data_ptr(), C, b, F, HW, heads, d, float(scale), _stream())
     return out
