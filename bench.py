@@ -119,13 +119,13 @@ def measure_forward(pipe, dev, dtype, size, iters=3):
     return st.elapsed_time(en) / iters * 1e-3, flops, launches
 
 
-def cpu_baseline(clip_flops, frames, budget_s=25.0):
+def cpu_baseline(clip_flops, frames, budget_s=15.0):
     """Oracle (CPU fp32 PyTorch port of the reference path, oracle/models.py) timed on this host: one denoising-UNet
     forward of the FULL-SIZE model on a reduced sample (latent 16x16, 2 x 4 frames), FLOPs counted by torch's
     FlopCounterMode, extrapolated to the whole clip's executed FLOPs."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import models as OM
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)  # threads actually used: more only adds oversubscription on shared hosts
     torch.set_num_threads(cores)
     t0 = time.time()
     with torch.device("meta"):
@@ -151,7 +151,7 @@ def cpu_baseline(clip_flops, frames, budget_s=25.0):
             m(x, torch.tensor(499), ehs, pose_cond_fea=pose)  # warm-up + FLOP count
         sample_flops = fc.get_total_flops()
         n, t1 = 0, time.time()
-        while n < 1 or (time.time() - t1 < budget_s and n < 20):
+        while n < 1 or (time.time() - t1 < budget_s and n < 10):
             m(x, torch.tensor(499), ehs, pose_cond_fea=pose)
             n += 1
         dt = (time.time() - t1) / n
