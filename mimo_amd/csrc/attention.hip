@@ -18,6 +18,7 @@
 
 namespace {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KV_TILE = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -52,11 +53,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   uint4 qf[KS];
   {
     const int qr = q0 + li;
-    const uint16_t* qp = a.q + ((int64_t)b * a.Nq + qr) * a.ldq + head * D;
+    const uint16_t* qb = a.q + (int64_t)b * a.Nq * a.ldq;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)((int64_t)a.Nq * a.ldq * 2), 0x00020000);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int kk = 16 * s + 8 * h2;
-      qf[s] = (qr < a.Nq && kk < D) ? *reinterpret_cast<const uint4*>(qp + kk) : make_uint4(0, 0, 0, 0);
+      const bool ok = (qr < a.Nq) & (kk < D);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)(((int64_t)qr * a.ldq + head * D + kk) * 2) : 0xFFFFFFF0u, 0, 0);
+      qf[s] = make_uint4(v.x, v.y, v.z, v.w);
     }
   }
 
@@ -76,24 +80,36 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const int nk = seg == 0 ? a.Nk : a.Nk2;
 
     for (int kv0 = 0; kv0 < nk; kv0 += KV_TILE) {
-      __syncthreads();  // previous tile fully consumed (also orders the initial zero-fill)
-      // ---- stage K tile [64][D] row-major ----
-      for (int id = tid; id < KV_TILE * DC; id += 256) {
-        const int row = id / DC, cc = id - row * DC;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (kv0 + row < nk) val = *reinterpret_cast<const uint4*>(kb + (int64_t)(kv0 + row) * ldk + head * D + cc * 8);
-        *reinterpret_cast<uint4*>(&Ks[row * KP + cc * 8]) = val;
-      }
-      // ---- stage V tile transposed: Vt[d][kv] ----
-      for (int id = tid; id < KV_TILE * DC; id += 256) {
-        const int row = id & (KV_TILE - 1), cc = id >> 6;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (kv0 + row < nk) val = *reinterpret_cast<const uint4*>(vb + (int64_t)(kv0 + row) * ldv + head * D + cc * 8);
-        const uint32_t w[4] = {val.x, val.y, val.z, val.w};
+      // ---- issue every global load of the K and V tiles first (buffer loads: rows past the segment end use an
+      //      out-of-range offset and read zeros), then write LDS: K row-major, V transposed ----
+      constexpr int NCH = (KV_TILE * DC + 255) / 256;
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)nk * ldk * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldv * 2), 0x00020000);
+      u32x4 kreg[NCH], vreg[NCH];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          Vt[(cc * 8 + 2 * i) * VP + row] = (uint16_t)(w[i] & 0xffffu);
-          Vt[(cc * 8 + 2 * i + 1) * VP + row] = (uint16_t)(w[i] >> 16);
+      for (int it = 0; it < NCH; ++it) {
+        const int id = tid + 256 * it;
+        const int krow = id / DC, kcc = id - krow * DC;
+        const bool kok = (id < KV_TILE * DC) & (kv0 + krow < nk);
+        kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rk, kok ? (unsigned)(((int64_t)(kv0 + krow) * ldk + head * D + kcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+        const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
+        const bool vok = (id < KV_TILE * DC) & (kv0 + vrow < nk);
+        vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rv, vok ? (unsigned)(((int64_t)(kv0 + vrow) * ldv + head * D + vcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+      }
+      __syncthreads();  // previous tile fully consumed (also orders the initial zero-fill)
+#pragma unroll
+      for (int it = 0; it < NCH; ++it) {
+        const int id = tid + 256 * it;
+        if (id < KV_TILE * DC) {
+          const int krow = id / DC, kcc = id - krow * DC;
+          *reinterpret_cast<uint4*>(&Ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
+          const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
+          const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            Vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
+            Vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
+          }
         }
       }
       __syncthreads();

@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* img_bias;
   const void* res;
   int64_t lda, ldw, ldo, ldr, M, rows_per_img, ldib;
+  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor extents (each operand < 4 GiB)
   int N, K;
   float out_scale;
   unsigned flags;
@@ -40,8 +41,10 @@ struct GemmArgs {
   int chunks1, chunks2, nkt;
 };
 
-template <int DT, int NR, bool CONV>
+// MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
+template <int DT, int NR, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+  constexpr bool CONV = MODE != 0;
   constexpr int BN = 32 * NR;
   constexpr int NRB = BN / 32;  // B rows staged per thread
   __shared__ __attribute__((aligned(16))) uint4 As[2][BM * 8];
@@ -64,94 +67,105 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const int sc = tid & 7;
   const int swz = sc ^ (srow & 7);  // (srow + 32 j) & 7 == srow & 7
 
-  // per-row A metadata
-  int64_t a_base[4];  // dense: row offset; conv: image index
+  // Operands are read through buffer descriptors: a 32-bit byte offset per lane and hardware range checking,
+  // so padding taps / ragged edges simply use an out-of-range offset and read zeros (no branches, no selects:
+  // all loads of a tile issue back-to-back and stay in flight under the MFMAs of the current tile).
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)g.w_bytes, 0x00020000);
+
+  unsigned a_base[4];  // MODE 0: byte offset of (row, chunk 0); 1: byte offset of tap (0,0); 2: image index
+  unsigned a2_base[4];
   int a_iy0[4], a_ix0[4];
   bool a_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t m = M0 + srow + 32 * j;
     a_ok[j] = m < g.M;
+    a2_base[j] = 0;
     if (CONV) {
       const int64_t hw = (int64_t)g.Hout * g.Wout;
       const int64_t img = a_ok[j] ? m / hw : 0;
       const int rem = a_ok[j] ? (int)(m - img * hw) : 0;
       const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
-      a_base[j] = img;
       a_iy0[j] = oy * g.stride - g.pad_t;
       a_ix0[j] = ox * g.stride - g.pad_l;
+      // arithmetic is modulo 2^32: exact for every in-range final offset
+      a_base[j] = MODE == 1 ? (unsigned)((((img * g.Hin + a_iy0[j]) * g.Win + a_ix0[j]) * g.Cin + sc * 8) * 2) : (unsigned)img;
+      a2_base[j] = (unsigned)((m * g.Cin2 + sc * 8) * 2);
     } else {
-      a_base[j] = m * g.lda;
+      a_base[j] = (unsigned)((m * g.lda + sc * 8) * 2);
       a_iy0[j] = a_ix0[j] = 0;
     }
   }
-  bool b_ok[NRB];
-  int64_t b_base[NRB];
+  unsigned b_base[NRB];
 #pragma unroll
   for (int j = 0; j < NRB; ++j) {
     const int n = N0 + srow + 32 * j;
-    b_ok[j] = n < g.N;
-    b_base[j] = (int64_t)n * g.ldw;
+    b_base[j] = n < g.N ? (unsigned)(((int64_t)n * g.ldw + sc * 8) * 2) : OOB;
   }
 
-  uint4 ra[4], rb[NRB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[4], rb[NRB];
+  auto bld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  };
   auto load_tile = [&](int kt) {
+    // offsets are computed on (uniform) branches; the loads themselves are issued once, after the join, so no
+    // PHI copy of a loaded value can pull a vmcnt wait in front of the MFMAs
+    unsigned offA[4], kw;
+    bool cok;
+    bool main_tap = true;
     if (CONV) {
       const int ntap_tiles = g.ks * g.ks * g.chunks1;
-      if (kt < ntap_tiles) {
+      main_tap = kt < ntap_tiles;
+      if (main_tap) {
         const int tap = kt / g.chunks1;
-        const int c = (kt - tap * g.chunks1) * BK + sc * 8;
+        const int c0 = (kt - tap * g.chunks1) * BK;
         const int ky = tap / g.ks, kx = tap - ky * g.ks;
-        const bool cok = c < g.Cin;
-        const int Hv = g.Hup > 0 ? g.Hup : g.Hin;
-        const int Wv = g.Hup > 0 ? g.Wup : g.Win;
+        cok = c0 + sc * 8 < g.Cin;
+        const int Hv = MODE == 2 ? g.Hup : g.Hin;
+        const int Wv = MODE == 2 ? g.Wup : g.Win;
+        const unsigned tap_off = (unsigned)((((int64_t)ky * g.Win + kx) * g.Cin + c0) * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int vy = a_iy0[j] + ky, vx = a_ix0[j] + kx;
-          const bool ok = a_ok[j] && cok && vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
-          int sy = vy, sx = vx;
-          if (g.Hup > 0) {
-            sy = min((int)floorf((float)vy * g.sh), g.Hin - 1);
-            sx = min((int)floorf((float)vx * g.sw), g.Win - 1);
+          const bool ok = a_ok[j] & cok & ((unsigned)vy < (unsigned)Hv) & ((unsigned)vx < (unsigned)Wv);
+          unsigned off;
+          if (MODE == 2) {
+            const int sy = min((int)floorf((float)vy * g.sh), g.Hin - 1);
+            const int sx = min((int)floorf((float)vx * g.sw), g.Win - 1);
+            off = (unsigned)(((((int64_t)a_base[j] * g.Hin + sy) * g.Win + sx) * g.Cin + c0 + sc * 8) * 2);
+          } else {
+            off = a_base[j] + tap_off;
           }
-          const int64_t off = ((a_base[j] * g.Hin + sy) * g.Win + sx) * g.Cin + c;
-          ra[j] = ok ? *reinterpret_cast<const uint4*>(g.A + off) : zero4;
+          offA[j] = ok ? off : OOB;
         }
-        const int64_t kw = (int64_t)tap * g.Cin + c;
-#pragma unroll
-        for (int j = 0; j < NRB; ++j)
-          rb[j] = (b_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + kw) : zero4;
+        kw = (unsigned)(((int64_t)tap * g.Cin + c0) * 2);
       } else {
-        const int c = (kt - ntap_tiles) * BK + sc * 8;
-        const bool cok = c < g.Cin2;
+        const int c0 = (kt - ntap_tiles) * BK;
+        cok = c0 + sc * 8 < g.Cin2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t m = M0 + srow + 32 * j;
-          ra[j] = (a_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.A2 + m * g.Cin2 + c) : zero4;
-        }
-        const int64_t kw = (int64_t)g.ks * g.ks * g.Cin + c;
-#pragma unroll
-        for (int j = 0; j < NRB; ++j)
-          rb[j] = (b_ok[j] && cok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + kw) : zero4;
+        for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a2_base[j] + (unsigned)(c0 * 2) : OOB;
+        kw = (unsigned)(((int64_t)g.ks * g.ks * g.Cin + c0) * 2);
       }
     } else {
-      const int k = kt * BK + sc * 8;
-      const bool kok = k < g.K;
+      cok = kt * BK + sc * 8 < g.K;
+      kw = (unsigned)(kt * BK * 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ra[j] = (a_ok[j] && kok) ? *reinterpret_cast<const uint4*>(g.A + a_base[j] + k) : zero4;
-#pragma unroll
-      for (int j = 0; j < NRB; ++j)
-        rb[j] = (b_ok[j] && kok) ? *reinterpret_cast<const uint4*>(g.W + b_base[j] + k) : zero4;
+      for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
+    const __amdgpu_buffer_rsrc_t rsel = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(main_tap ? g.A : g.A2), 0, (int)(main_tap ? g.a_bytes : g.a2_bytes), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = bld(rsel, offA[j]);
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) rb[j] = bld(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB);
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) As[buf][(srow + 32 * j) * 8 + swz] = ra[j];
+    for (int j = 0; j < 4; ++j) As[buf][(srow + 32 * j) * 8 + swz] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
 #pragma unroll
-    for (int j = 0; j < NRB; ++j) Bs[buf][(srow + 32 * j) * 8 + swz] = rb[j];
+    for (int j = 0; j < NRB; ++j) Bs[buf][(srow + 32 * j) * 8 + swz] = make_uint4(rb[j].x, rb[j].y, rb[j].z, rb[j].w);
   };
 
   f32x4 acc[NR][4];
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   }
 }
 
-template <int DT, bool CONV>
+template <int DT, int MODE>
 int launch(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
@@ -266,9 +280,9 @@ int launch(const GemmArgs& g0, hipStream_t st) {
   const int64_t nwg = tiles_m * g.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
   if (use5)
-    hipLaunchKernelGGL((gemm_kernel<DT, 5, CONV>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, 5, MODE>), dim3((unsigned)nwg), dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<DT, 4, CONV>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, 4, MODE>), dim3((unsigned)nwg), dim3(256), 0, st, g);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }
@@ -294,9 +308,12 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
   g.ldib = img_bias_ld > 0 ? img_bias_ld : N;
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
   g.nkt = (K + BK - 1) / BK;
+  const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
+  if (ab >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;  // operands are addressed with 32-bit offsets
+  g.a_bytes = (unsigned)ab; g.a2_bytes = 0; g.w_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIMO_F16) return launch<MIMO_F16, false>(g, st);
-  if (dtype == MIMO_BF16) return launch<MIMO_BF16, false>(g, st);
+  if (dtype == MIMO_F16) return launch<MIMO_F16, 0>(g, st);
+  if (dtype == MIMO_BF16) return launch<MIMO_BF16, 0>(g, st);
   return MIMO_EDTYPE;
 }
 
@@ -329,8 +346,14 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.chunks2 = (p->Cin2 + BK - 1) / BK;
   g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIMO_F16) return launch<MIMO_F16, true>(g, st);
-  if (dtype == MIMO_BF16) return launch<MIMO_BF16, true>(g, st);
+  {
+    const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
+    if (ab >= 0xFFFFFFF0LL || a2b >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;
+    g.a_bytes = (unsigned)ab; g.a2_bytes = (unsigned)a2b; g.w_bytes = (unsigned)wb;
+  }
+  const bool ups = p->Hup > 0;
+  if (dtype == MIMO_F16) return ups ? launch<MIMO_F16, 2>(g, st) : launch<MIMO_F16, 1>(g, st);
+  if (dtype == MIMO_BF16) return ups ? launch<MIMO_BF16, 2>(g, st) : launch<MIMO_BF16, 1>(g, st);
   return MIMO_EDTYPE;
 }
 
