@@ -69,115 +69,137 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running max in RAW score units (the scale is folded into the exp2 fma)
+  const float c = a.scale_log2;
 
-  const int nseg = (a.k2 && a.Nk2 > 0 && b >= a.seg2_first_batch) ? 2 : 1;
-  for (int seg = 0; seg < nseg; ++seg) {
-    const uint16_t* kb = seg == 0 ? a.k + (int64_t)b * a.Nk * a.ldk : a.k2;
-    const uint16_t* vb = seg == 0 ? a.v + (int64_t)b * a.Nk * a.ldv : a.v2;
-    const int64_t ldk = seg == 0 ? a.ldk : a.ldk2;
-    const int64_t ldv = seg == 0 ? a.ldv : a.ldv2;
-    const int nk = seg == 0 ? a.Nk : a.Nk2;
+  // flattened KV-tile list: the self segment, then (cond rows only) the bank segment
+  const bool has2 = a.k2 && a.Nk2 > 0 && b >= a.seg2_first_batch;
+  const int T0 = (a.Nk + KV_TILE - 1) / KV_TILE;
+  const int T = T0 + (has2 ? (a.Nk2 + KV_TILE - 1) / KV_TILE : 0);
+  const uint16_t* kb0 = a.k + (int64_t)b * a.Nk * a.ldk;
+  const uint16_t* vb0 = a.v + (int64_t)b * a.Nk * a.ldv;
+  constexpr int NCH = (KV_TILE * DC + 255) / 256;
+  u32x4 kreg[NCH], vreg[NCH];
 
-    for (int kv0 = 0; kv0 < nk; kv0 += KV_TILE) {
-      // ---- issue every global load of the K and V tiles first (buffer loads: rows past the segment end use an
-      //      out-of-range offset and read zeros), then write LDS: K row-major, V transposed ----
-      constexpr int NCH = (KV_TILE * DC + 255) / 256;
-      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)nk * ldk * 2), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldv * 2), 0x00020000);
-      u32x4 kreg[NCH], vreg[NCH];
+  // issue every global load of tile t (buffer loads; rows past the segment end read zeros)
+  auto issue = [&](int t) {
+    const bool s2 = t >= T0;
+    const uint16_t* kb = s2 ? a.k2 : kb0;
+    const uint16_t* vb = s2 ? a.v2 : vb0;
+    const int64_t ldk = s2 ? a.ldk2 : a.ldk, ldv = s2 ? a.ldv2 : a.ldv;
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)nk * ldk * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldv * 2), 0x00020000);
 #pragma unroll
-      for (int it = 0; it < NCH; ++it) {
-        const int id = tid + 256 * it;
+    for (int it = 0; it < NCH; ++it) {
+      const int id = tid + 256 * it;
+      const int krow = id / DC, kcc = id - krow * DC;
+      const bool kok = (id < KV_TILE * DC) & (kv0 + krow < nk);
+      kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rk, kok ? (unsigned)(((int64_t)(kv0 + krow) * ldk + head * D + kcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+      const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
+      const bool vok = (id < KV_TILE * DC) & (kv0 + vrow < nk);
+      vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rv, vok ? (unsigned)(((int64_t)(kv0 + vrow) * ldv + head * D + vcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+    }
+  };
+
+  issue(0);
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();  // tile t-1 fully consumed (first iteration: orders the zero-fill)
+    // ---- registers -> LDS: K row-major, V transposed ----
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int id = tid + 256 * it;
+      if (id < KV_TILE * DC) {
         const int krow = id / DC, kcc = id - krow * DC;
-        const bool kok = (id < KV_TILE * DC) & (kv0 + krow < nk);
-        kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rk, kok ? (unsigned)(((int64_t)(kv0 + krow) * ldk + head * D + kcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+        *reinterpret_cast<uint4*>(&Ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
         const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
-        const bool vok = (id < KV_TILE * DC) & (kv0 + vrow < nk);
-        vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rv, vok ? (unsigned)(((int64_t)(kv0 + vrow) * ldv + head * D + vcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
-      }
-      __syncthreads();  // previous tile fully consumed (also orders the initial zero-fill)
+        const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
-      for (int it = 0; it < NCH; ++it) {
-        const int id = tid + 256 * it;
-        if (id < KV_TILE * DC) {
-          const int krow = id / DC, kcc = id - krow * DC;
-          *reinterpret_cast<uint4*>(&Ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
-          const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
-          const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            Vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
-            Vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
-          }
+        for (int i = 0; i < 4; ++i) {
+          Vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
+          Vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
         }
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    if (t + 1 < T) issue(t + 1);  // next tile's loads fly under this tile's MFMAs / softmax
 
-      // ---- S^T = K.Q^T : two 32-kv sub-tiles ----
-      f32x16 st[2];
+    const bool s2 = t >= T0;
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+
+    // ---- S^T = K.Q^T : two 32-kv sub-tiles ----
+    f32x16 st[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * t + li) * KP + 16 * s + 8 * h2]);
-          st[t] = HT<DT>::mfma32(kf, qf[s], st[t]);
-        }
+      for (int s = 0; s < KS; ++s) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
+        st[u] = HT<DT>::mfma32(kf, qf[s], st[u]);
       }
-      // ---- online softmax over kv for this lane's query ----
-      float mt = -INFINITY;
+    }
+    // ---- online softmax over kv for this lane's query (raw-score max; scale folded into the exp2 fma) ----
+    if (kv0 + KV_TILE > nk) {  // ragged last tile of a segment (wave-uniform)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
-          const float sv = (kv < nk) ? st[t][r] * a.scale_log2 : -INFINITY;
-          st[t][r] = sv;
-          mt = fmaxf(mt, sv);
+          const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (kv >= nk) st[u][r] = -INFINITY;
         }
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
-      float ps = 0.f;
+    }
+    float mt = st[0][0];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(st[t][r] - m_use);
-          st[t][r] = p;
-          ps += p;
-        }
-      ps += __shfl_xor(ps, 32, 64);
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[u][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {  // some lane's max moved: rescale (rare after a few tiles)
+      const float alpha = exp2f((m_run - m_use) * c);  // m_run = -inf -> 0
+      l_run *= alpha;
 #pragma unroll
-      for (int t = 0; t < OT; ++t)
+      for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    const float mc = -m_use * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(fmaf(st[u][r], c, mc));
+        st[u][r] = pv;
+        ps += pv;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run += ps;
 
-      // ---- P^T fragments (B operand) straight from the accumulators ----
-      uint4 pf[4];
+    // ---- P^T fragments (B operand) straight from the accumulators ----
+    uint4 pf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = u >> 1, hh = u & 1;
+      pf[u].x = pack2<DT>(st[tt][8 * hh + 0], st[tt][8 * hh + 1]);
+      pf[u].y = pack2<DT>(st[tt][8 * hh + 2], st[tt][8 * hh + 3]);
+      pf[u].z = pack2<DT>(st[tt][8 * hh + 4], st[tt][8 * hh + 5]);
+      pf[u].w = pack2<DT>(st[tt][8 * hh + 6], st[tt][8 * hh + 7]);
+    }
+    // ---- O^T += V^T.P^T ----
+#pragma unroll
+    for (int dt = 0; dt < OT; ++dt) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int t = u >> 1, hh = u & 1;
-        pf[u].x = pack2<DT>(st[t][8 * hh + 0], st[t][8 * hh + 1]);
-        pf[u].y = pack2<DT>(st[t][8 * hh + 2], st[t][8 * hh + 3]);
-        pf[u].z = pack2<DT>(st[t][8 * hh + 4], st[t][8 * hh + 5]);
-        pf[u].w = pack2<DT>(st[t][8 * hh + 6], st[t][8 * hh + 7]);
-      }
-      // ---- O^T += V^T.P^T ----
-#pragma unroll
-      for (int dt = 0; dt < OT; ++dt) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint16_t* vr = &Vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
-          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
-          ot[dt] = HT<DT>::mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], ot[dt]);
-        }
+        const uint16_t* vr = &Vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
+        const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
+        ot[dt] = HT<DT>::mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], ot[dt]);
       }
     }
   }

@@ -14,8 +14,9 @@ __device__ __forceinline__ float load_elem(const void* p, bool f32, int64_t idx)
 }
 
 // ---------------------------------------------------------------------------------
-// GroupNorm statistics: one block per (image, group).  Two passes over the group's
-// elements (second pass is L2-resident: a group of one image is <= HW*cpg*4 bytes).
+// GroupNorm statistics: one block per (image, group), ONE pass over the group's elements with
+// shifted sums (shift = the group's first element, which removes the E[x^2]-E[x]^2 cancellation),
+// 2-element vector loads, division-free incremental indexing.
 // ---------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, const void* x2, int C2,
@@ -24,38 +25,48 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   const int img = blockIdx.x / groups;
   const int grp = blockIdx.x % groups;
   const int C = C1 + C2;
-  const int cpg = C / groups;
+  const int cpg = C / groups;          // even (host-checked)
   const int c0 = grp * cpg;
-  const int count = (int)(HW * cpg);  // host guarantees < 2^31
+  const int hp = cpg >> 1;             // channel pairs per pixel
+  const int count2 = (int)(HW * hp);   // host guarantees < 2^31
   __shared__ float red[8];
-  __shared__ float s_mean;
 
-  auto fetch = [&](int e) -> float {
-    const int p = e / cpg;
-    const int c = c0 + (e - p * cpg);
-    if (c < C1) return load_elem<DT>(x1, f32, ((int64_t)img * HW + p) * C1 + c);
-    return load_elem<DT>(x2, f32, ((int64_t)img * HW + p) * C2 + (c - C1));
+  auto fetch2 = [&](int p, int c, float& a, float& b) {
+    const bool first = c < C1;
+    const void* src = first ? x1 : x2;
+    const int64_t idx = first ? ((int64_t)img * HW + p) * C1 + c : ((int64_t)img * HW + p) * C2 + (c - C1);
+    if (f32) {
+      const float2 v = *reinterpret_cast<const float2*>((const float*)src + idx);
+      a = v.x; b = v.y;
+    } else {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint16_t*)src + idx);
+      a = HT<DT>::to_f((uint16_t)(v & 0xffffu)); b = HT<DT>::to_f((uint16_t)(v >> 16));
+    }
   };
-
-  float s = 0.f;
-  for (int e = threadIdx.x; e < count; e += 256) s += fetch(e);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) s_mean = (red[0] + red[1] + red[2] + red[3]) / (float)count;
-  __syncthreads();
-  const float mean = s_mean;
-  float q = 0.f;
-  for (int e = threadIdx.x; e < count; e += 256) {
-    const float d = fetch(e) - mean;
-    q += d * d;
+  float sh, sh2;
+  fetch2(0, c0, sh, sh2);  // same value in every thread
+  const int dp = 256 / hp, dc = 256 - dp * hp;
+  int p = threadIdx.x / hp, c2 = threadIdx.x - p * hp;
+  float s = 0.f, q = 0.f;
+  for (int e = threadIdx.x; e < count2; e += 256) {
+    float a, b;
+    fetch2(p, c0 + 2 * c2, a, b);
+    a -= sh; b -= sh;
+    s += a + b;
+    q += a * a + b * b;
+    p += dp; c2 += dc;
+    if (c2 >= hp) { c2 -= hp; ++p; }
   }
+  s = wave_sum(s);
   q = wave_sum(q);
-  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q;
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)count;
-    stats[(int64_t)blockIdx.x * 2 + 0] = mean;
+    const float n = (float)count2 * 2.f;
+    const float S = red[0] + red[1] + red[2] + red[3], Q = red[4] + red[5] + red[6] + red[7];
+    const float ms = S / n;
+    const float var = fmaxf(Q / n - ms * ms, 0.f);
+    stats[(int64_t)blockIdx.x * 2 + 0] = sh + ms;
     stats[(int64_t)blockIdx.x * 2 + 1] = rsqrtf(var + eps);
   }
 }
@@ -199,7 +210,7 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
                                      int dtype, int n, int64_t HW, int groups, float eps, float* stats,
                                      void* stream) {
   if (!x1 || !stats || n <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
-  if ((C1 + C2) % groups) return MIMO_EINVAL;
+  if ((C1 + C2) % groups || ((C1 + C2) / groups) % 2 || (C1 & 1)) return MIMO_EINVAL;
   if (C2 > 0 && !x2) return MIMO_EINVAL;
   if (HW * ((C1 + C2) / groups) >= 0x7fffffffLL) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
