@@ -18,16 +18,16 @@ __device__ __forceinline__ float load_elem(const void* p, bool f32, int64_t idx)
 // shifted sums (shift = the group's first element, which removes the E[x^2]-E[x]^2 cancellation),
 // 2-element vector loads, division-free incremental indexing.
 // ---------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int V>  // V = elements per load (2 when channels-per-group and C1 are even, else 1)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, const void* x2, int C2,
                                                        int f32, int64_t HW, int groups, float eps,
                                                        float* stats) {
   const int img = blockIdx.x / groups;
   const int grp = blockIdx.x % groups;
   const int C = C1 + C2;
-  const int cpg = C / groups;          // even (host-checked)
+  const int cpg = C / groups;
   const int c0 = grp * cpg;
-  const int hp = cpg >> 1;             // channel pairs per pixel
+  const int hp = cpg / V;              // loads per pixel
   const int count2 = (int)(HW * hp);   // host guarantees < 2^31
   __shared__ float red[8];
 
@@ -35,12 +35,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
     const bool first = c < C1;
     const void* src = first ? x1 : x2;
     const int64_t idx = first ? ((int64_t)img * HW + p) * C1 + c : ((int64_t)img * HW + p) * C2 + (c - C1);
-    if (f32) {
-      const float2 v = *reinterpret_cast<const float2*>((const float*)src + idx);
-      a = v.x; b = v.y;
+    if (V == 2) {
+      if (f32) {
+        const float2 v = *reinterpret_cast<const float2*>((const float*)src + idx);
+        a = v.x; b = v.y;
+      } else {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint16_t*)src + idx);
+        a = HT<DT>::to_f((uint16_t)(v & 0xffffu)); b = HT<DT>::to_f((uint16_t)(v >> 16));
+      }
     } else {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint16_t*)src + idx);
-      a = HT<DT>::to_f((uint16_t)(v & 0xffffu)); b = HT<DT>::to_f((uint16_t)(v >> 16));
+      a = f32 ? ((const float*)src)[idx] : HT<DT>::to_f(((const uint16_t*)src)[idx]);
+      b = a;
     }
   };
   float sh, sh2;
@@ -50,10 +55,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   float s = 0.f, q = 0.f;
   for (int e = threadIdx.x; e < count2; e += 256) {
     float a, b;
-    fetch2(p, c0 + 2 * c2, a, b);
+    fetch2(p, c0 + V * c2, a, b);
     a -= sh; b -= sh;
-    s += a + b;
-    q += a * a + b * b;
+    if (V == 2) {
+      s += a + b;
+      q += a * a + b * b;
+    } else {
+      s += a;
+      q += a * a;
+    }
     p += dp; c2 += dc;
     if (c2 >= hp) { c2 -= hp; ++p; }
   }
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float n = (float)count2 * 2.f;
+    const float n = (float)count2 * (float)V;
     const float S = red[0] + red[1] + red[2] + red[3], Q = red[4] + red[5] + red[6] + red[7];
     const float ms = S / n;
     const float var = fmaxf(Q / n - ms * ms, 0.f);
@@ -210,17 +220,21 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
                                      int dtype, int n, int64_t HW, int groups, float eps, float* stats,
                                      void* stream) {
   if (!x1 || !stats || n <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
-  if ((C1 + C2) % groups || ((C1 + C2) / groups) % 2 || (C1 & 1)) return MIMO_EINVAL;
+  if ((C1 + C2) % groups) return MIMO_EINVAL;
   if (C2 > 0 && !x2) return MIMO_EINVAL;
   if (HW * ((C1 + C2) / groups) >= 0x7fffffffLL) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(n * groups);
-  if (dtype == MIMO_F16)
-    hipLaunchKernelGGL(gn_stats_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats);
-  else if (dtype == MIMO_BF16)
-    hipLaunchKernelGGL(gn_stats_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats);
-  else
+  const bool v2 = (((C1 + C2) / groups) % 2 == 0) && (C1 % 2 == 0) && (C2 % 2 == 0);
+#define GNS_LAUNCH(DT, V) hipLaunchKernelGGL((gn_stats_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats)
+  if (dtype == MIMO_F16) {
+    if (v2) GNS_LAUNCH(MIMO_F16, 2); else GNS_LAUNCH(MIMO_F16, 1);
+  } else if (dtype == MIMO_BF16) {
+    if (v2) GNS_LAUNCH(MIMO_BF16, 2); else GNS_LAUNCH(MIMO_BF16, 1);
+  } else {
     return MIMO_EDTYPE;
+  }
+#undef GNS_LAUNCH
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }

@@ -15,7 +15,9 @@ def main():
     dev = torch.device("cuda:0")
     pipe = bench.build_pipeline(dev, dtype)
     t, fl, n = bench.measure_forward(pipe, dev, dtype, 512, iters=3)
-    print(f"forward {t*1e3:.1f} ms  {fl/1e12:.2f} TFLOP  {fl/t/1e12:.1f} TF/s  {n} launches")
+    print(f"forward {t*1e3:.1f} ms  {fl/1e12:.2f} TFLOP  {fl/t/1e12:.1f} TF/s  {n} launches", flush=True)
+    torch.cuda.synchronize()
+    os._exit(0)  # skip interpreter teardown: under rocprofv3 it can hang after the tool has finalised
 
 
 if __name__ == "__main__":
