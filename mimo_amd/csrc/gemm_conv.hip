@@ -9,9 +9,9 @@
 //
 // Tiling (gfx950): block = 256 threads = 4 waves (2 x 2); block tile 128 x (32*NR) x 64;
 // each wave owns 64 x (16*NR) as 4 x NR MFMA 16x16x32 tiles, fp32 accumulators in
-// registers.  Operands are staged global -> VGPR -> LDS (16-byte chunks, XOR-swizzled so
+// registers.  Operands are staged global -> LDS by DMA (16-byte chunks, XOR-swizzled on the source side so
 // the ds_read_b128 fragment reads are bank-conflict-free), double-buffered with one
-// barrier per K-tile; the next tile's global loads are in flight under the MFMAs.
+// barrier per K-tile; the next tile's global->LDS DMA (buffer_load ... lds) is in flight under the MFMAs.
 // The MFMA is issued "swapped" (W fragment as the A operand) so that every lane ends up
 // with 4 consecutive output columns of one row -> 16-byte epilogue loads/stores.
 #include "common.cuh"
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
   constexpr int BN = 32 * NR;
   constexpr int NRB = BN / 32;  // B rows staged per thread
-  __shared__ __attribute__((aligned(16))) uint4 As[2][BM * 8];
-  __shared__ __attribute__((aligned(16))) uint4 Bs[2][BN * 8];
+  // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt(0) before every fragment read while a
+  // DMA is in flight): [A buf0 | A buf1 | B buf0 | B buf1], 16-byte units
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * BM * 8 + 2 * BN * 8];
+  constexpr int A_OFF = 0, B_OFF = 2 * BM * 8;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -63,15 +65,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const int N0 = tile_n * BN;
 
   // ---- staging roles: thread -> (row srow + 32 j, 16-byte chunk sc) ----
+  // LDS-DMA writes lane-linear (wave-uniform base + lane*16), so the XOR swizzle that makes the fragment
+  // reads conflict-free is applied to the SOURCE: the lane that fills physical chunk (tid&7) of row srow+32j
+  // fetches logical chunk sc = (tid&7) ^ (row&7).
   const int srow = tid >> 3;
-  const int sc = tid & 7;
-  const int swz = sc ^ (srow & 7);  // (srow + 32 j) & 7 == srow & 7
+  const int sc = (tid & 7) ^ (srow & 7);  // (srow + 32 j) & 7 == srow & 7
 
   // Operands are read through buffer descriptors: a 32-bit byte offset per lane and hardware range checking,
   // so padding taps / ragged edges simply use an out-of-range offset and read zeros (no branches, no selects:
   // all loads of a tile issue back-to-back and stay in flight under the MFMAs of the current tile).
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)g.w_bytes, 0x00020000);
 
   unsigned a_base[4];  // MODE 0: byte offset of (row, chunk 0); 1: byte offset of tap (0,0); 2: image index
   unsigned a2_base[4];
@@ -104,12 +107,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     b_base[j] = n < g.N ? (unsigned)(((int64_t)n * g.ldw + sc * 8) * 2) : OOB;
   }
 
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 ra[4], rb[NRB];
-  auto bld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> u32x4 {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  // raw buffer descriptor: base, stride 0, num_records (bytes), flags — the same words the builtin builds
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
   };
-  auto load_tile = [&](int kt) {
+  // One DMA = 64 lanes x 16 B = 8 tile rows; lane l lands at lds_base + 16 l.  Issued through inline asm so that
+  // hipcc does NOT track it: with the builtin it drains vmcnt(0) before the first fragment read of every tile
+  // (it cannot prove the reads touch the other buffer), which serialises DMA and MFMA.  The kernel waits for
+  // its DMAs itself (s_waitcnt vmcnt(0) right before the end-of-tile barrier).  M0 is saved/restored.
+  auto dma = [&](const i32x4& r, unsigned off, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(r), "s"(lds_base) : "memory");
+  };
+  const i32x4 rW = make_rsrc(g.W, g.w_bytes);
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+  auto load_tile = [&](int kt, int buf) {
     // offsets are computed on (uniform) branches; the loads themselves are issued once, after the join, so no
     // PHI copy of a loaded value can pull a vmcnt wait in front of the MFMAs
     unsigned offA[4], kw;
@@ -154,20 +173,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
-    const __amdgpu_buffer_rsrc_t rsel = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(main_tap ? g.A : g.A2), 0, (int)(main_tap ? g.a_bytes : g.a2_bytes), 0x00020000);
+    const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = bld(rsel, offA[j]);
+    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], smem_base + 16u * (A_OFF + buf * (BM * 8) + (wave_u * 8 + 32 * j) * 8));
 #pragma unroll
-    for (int j = 0; j < NRB; ++j) rb[j] = bld(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB);
+    for (int j = 0; j < NRB; ++j)
+      dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, smem_base + 16u * (B_OFF + buf * (BN * 8) + (wave_u * 8 + 32 * j) * 8));
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) As[buf][(srow + 32 * j) * 8 + swz] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
-#pragma unroll
-    for (int j = 0; j < NRB; ++j) Bs[buf][(srow + 32 * j) * 8 + swz] = make_uint4(rb[j].x, rb[j].y, rb[j].z, rb[j].w);
-  };
-
   f32x4 acc[NR][4];
 #pragma unroll
   for (int ni = 0; ni < NR; ++ni)
@@ -175,21 +187,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = g.nkt;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  load_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // buffer 0 published
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+    if (kt + 1 < nkt) load_tile(kt + 1, buf ^ 1);  // DMA into the other buffer flies under this tile's MFMAs
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ch = (4 * s + lg) ^ (li & 7);
       uint4 fa[4], fb[NR];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = As[buf][(wm * 64 + mi * 16 + li) * 8 + ch];
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = smem[A_OFF + buf * (BM * 8) + (wm * 64 + mi * 16 + li) * 8 + ch];
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni) fb[ni] = Bs[buf][(wn * 16 * NR + ni * 16 + li) * 8 + ch];
+      for (int ni = 0; ni < NR; ++ni) fb[ni] = smem[B_OFF + buf * (BN * 8) + (wn * 16 * NR + ni * 16 + li) * 8 + ch];
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
           acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of the next tile have landed
+    __syncthreads();                                  // ... everyone's have, and every wave is done reading `buf`
   }
 
   // ---- epilogue: lane holds out[m = .. + li][n = .. + 4*lg + r], r = 0..3 ----

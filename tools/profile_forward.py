@@ -17,7 +17,11 @@ def main():
     t, fl, n = bench.measure_forward(pipe, dev, dtype, 512, iters=3)
     print(f"forward {t*1e3:.1f} ms  {fl/1e12:.2f} TFLOP  {fl/t/1e12:.1f} TF/s  {n} launches", flush=True)
     torch.cuda.synchronize()
-    os._exit(0)  # skip interpreter teardown: under rocprofv3 it can hang after the tool has finalised
+    # under rocprofv3 the interpreter can hang after the tool has written its output: give teardown 60 s, then leave
+    import threading
+    t = threading.Timer(60.0, os._exit, [0])
+    t.daemon = True
+    t.start()
 
 
 if __name__ == "__main__":
