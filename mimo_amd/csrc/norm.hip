@@ -113,12 +113,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, int C1, c
     if (raw) *reinterpret_cast<uint4*>(raw + tok * C + c) = pack8<DT>(v);
     if (out) {
       float y[8];
+      // an 8-channel chunk spans at most two groups (cpg >= 4 in every model on this path; general fallback below)
+      const int g0 = c / cpg;
+      const int split = (g0 + 1) * cpg - c;  // first index k that belongs to the next group
+      const float2 s0 = *reinterpret_cast<const float2*>(stats + ((int64_t)img * groups + g0) * 2);
+      const float2 s1 = *reinterpret_cast<const float2*>(stats + ((int64_t)img * groups + min(g0 + 1, groups - 1)) * 2);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + c), gb = *reinterpret_cast<const float4*>(gamma + c + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(beta + c), bb = *reinterpret_cast<const float4*>(beta + c + 4);
+      const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+      const float bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int grp = (c + k) / cpg;
-        const float mean = stats[((int64_t)img * groups + grp) * 2];
-        const float rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
-        float t = (v[k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        float mean, rstd;
+        if (cpg >= 8 || k < split + cpg) {
+          mean = k < split ? s0.x : s1.x;
+          rstd = k < split ? s0.y : s1.y;
+        } else {  // tiny groups (cpg < 7): a chunk may span more than two
+          const int grp = (c + k) / cpg;
+          mean = stats[((int64_t)img * groups + grp) * 2];
+          rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
+        }
+        const float t = (v[k] - mean) * rstd * gm[k] + bt[k];
         y[k] = silu ? silu_f(t) : t;
       }
       *reinterpret_cast<uint4*>(out + tok * C + c) = pack8<DT>(y);
@@ -136,59 +151,85 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const void* x, int f32,
                                                          int64_t rows_per_frame, int pe_frames,
                                                          uint16_t* out) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
   const int c8 = C / 8;
-  float v[VPL][8];
-  float s = 0.f;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  // affine parameters stay in registers for every row this wave normalises
+  float gm[VPL][8], bt[VPL][8];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const int ci = lane + 64 * j;
-    if (ci < c8) {
-      if (f32) {
-        const float* p = (const float*)x + row * C + ci * 8;
-        const float4 a = *reinterpret_cast<const float4*>(p);
-        const float4 b = *reinterpret_cast<const float4*>(p + 4);
-        v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
-        v[j][4] = b.x; v[j][5] = b.y; v[j][6] = b.z; v[j][7] = b.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gm[j][k] = ci < c8 ? gamma[ci * 8 + k] : 0.f;
+      bt[j][k] = ci < c8 ? beta[ci * 8 + k] : 0.f;
+    }
+  }
+  auto load_row = [&](int64_t row, float (&v)[VPL][8]) {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ci = lane + 64 * j;
+      if (ci < c8) {
+        if (f32) {
+          const float* p = (const float*)x + row * C + ci * 8;
+          const float4 a = *reinterpret_cast<const float4*>(p);
+          const float4 b = *reinterpret_cast<const float4*>(p + 4);
+          v[j][0] = a.x; v[j][1] = a.y; v[j][2] = a.z; v[j][3] = a.w;
+          v[j][4] = b.x; v[j][5] = b.y; v[j][6] = b.z; v[j][7] = b.w;
+        } else {
+          unpack8<DT>(*reinterpret_cast<const uint4*>((const uint16_t*)x + row * C + ci * 8), v[j]);
+        }
       } else {
-        unpack8<DT>(*reinterpret_cast<const uint4*>((const uint16_t*)x + row * C + ci * 8), v[j]);
-      }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[j][k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
-    }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const int ci = lane + 64 * j;
-    if (ci < c8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float d = v[j][k] - mean;
-        q += d * d;
+        for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
       }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  const float* pe_row = pe ? pe + ((row / rows_per_frame) % pe_frames) * (int64_t)C : nullptr;
+  };
+  float cur[VPL][8], nxt[VPL][8];
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  load_row(row, cur);
+  for (; row < rows; row += nwaves) {
+    const int64_t nrow = row + nwaves;
+    if (nrow < rows) load_row(nrow, nxt);  // next row's loads fly under this row's reductions
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const int ci = lane + 64 * j;
-    if (ci < c8) {
-      float y[8];
+    for (int j = 0; j < VPL; ++j)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int c = ci * 8 + k;
-        y[k] = (v[j][k] - mean) * rstd * gamma[c] + beta[c];
-        if (pe_row) y[k] += pe_row[c];
+      for (int k = 0; k < 8; ++k) s += cur[j][k];  // padded lanes hold zeros
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      if (lane + 64 * j < c8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float d = cur[j][k] - mean;
+          q += d * d;
+        }
       }
-      *reinterpret_cast<uint4*>(out + row * C + ci * 8) = pack8<DT>(y);
     }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const float* pe_row = pe ? pe + ((row / rows_per_frame) % pe_frames) * (int64_t)C : nullptr;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ci = lane + 64 * j;
+      if (ci < c8) {
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = (cur[j][k] - mean) * rstd * gm[j][k] + bt[j][k];
+        if (pe_row) {
+          const float4 pa = *reinterpret_cast<const float4*>(pe_row + ci * 8);
+          const float4 pb = *reinterpret_cast<const float4*>(pe_row + ci * 8 + 4);
+          y[0] += pa.x; y[1] += pa.y; y[2] += pa.z; y[3] += pa.w;
+          y[4] += pb.x; y[5] += pb.y; y[6] += pb.z; y[7] += pb.w;
+        }
+        *reinterpret_cast<uint4*>(out + row * C + ci * 8) = pack8<DT>(y);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cur[j][k] = nxt[j][k];
   }
 }
 
@@ -266,7 +307,9 @@ extern "C" int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t r
   if (!x || !out || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 2048) return MIMO_EINVAL;
   if (pe && (rows_per_frame <= 0 || pe_frames <= 0)) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((rows + 3) / 4);
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 256 * 8) nb = 256 * 8;  // persistent waves, grid-stride over rows
+  const unsigned grid = (unsigned)nb;
   const int vpl = (C / 8 + 63) / 64;
 #define LN_LAUNCH(DT, V)                                                                              \
   hipLaunchKernelGGL((layer_norm_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x, x_is_f32, rows, C, \
