@@ -14,8 +14,6 @@
 // (q = lane & 31): the online-softmax max/sum are in-lane reductions plus one xor-32
 // shuffle, the O rescale needs no broadcast, and P feeds the second MFMA straight from the
 // accumulator registers (the k-index permutation is applied identically to V^T's fragment).
-#include <stdlib.h>
-
 #include "common.cuh"
 
 namespace {
@@ -32,7 +30,7 @@ struct AttnArgs {
   float scale_log2;
 };
 
-template <int DT, int D, int QT>  // QT = 32-query tiles per wave (K/V fragments are reused QT times)
+template <int DT, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
   constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
@@ -45,41 +43,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, li = lane & 31;
   const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
+  const int q0 = blockIdx.x * 128 + wave * 32;
 
   // zero the LDS once: pad columns / rows are never written again
   for (int i = tid; i < KV_TILE * KP / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
   for (int i = tid; i < OT * 32 * VP / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
 
   // Q^T fragments (B operand): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8]
-  uint4 qf[QT][KS];
+  uint4 qf[KS];
   {
+    const int qr = q0 + li;
     const uint16_t* qb = a.q + (int64_t)b * a.Nq * a.ldq;
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)((int64_t)a.Nq * a.ldq * 2), 0x00020000);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      const int qr = q0 + 32 * qt + li;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int kk = 16 * s + 8 * h2;
-        const bool ok = (qr < a.Nq) & (kk < D);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)(((int64_t)qr * a.ldq + head * D + kk) * 2) : 0xFFFFFFF0u, 0, 0);
-        qf[qt][s] = make_uint4(v.x, v.y, v.z, v.w);
-      }
+    for (int s = 0; s < KS; ++s) {
+      const int kk = 16 * s + 8 * h2;
+      const bool ok = (qr < a.Nq) & (kk < D);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)(((int64_t)qr * a.ldq + head * D + kk) * 2) : 0xFFFFFFF0u, 0, 0);
+      qf[s] = make_uint4(v.x, v.y, v.z, v.w);
     }
   }
 
-  f32x16 ot[QT][OT];
-  float m_run[QT], l_run[QT];  // running max in RAW score units (the scale is folded into the exp2 fma)
+  f32x16 ot[OT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    m_run[qt] = -INFINITY;
-    l_run[qt] = 0.f;
+  for (int t = 0; t < OT; ++t)
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[qt][t][r] = 0.f;
-  }
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running max in RAW score units (the scale is folded into the exp2 fma)
   const float c = a.scale_log2;
 
   // flattened KV-tile list: the self segment, then (cond rows only) the bank segment
@@ -139,76 +129,69 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
 
-    // ---- S^T = K.Q^T : two 32-kv sub-tiles per query tile; each K fragment feeds QT MFMAs ----
-    f32x16 st[QT][2];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[qt][u][r] = 0.f;
+    // ---- S^T = K.Q^T : two 32-kv sub-tiles ----
+    f32x16 st[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+#pragma unroll
       for (int s = 0; s < KS; ++s) {
         const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) st[qt][u] = HT<DT>::mfma32(kf, qf[qt][s], st[qt][u]);
+        st[u] = HT<DT>::mfma32(kf, qf[s], st[u]);
       }
     }
-    // ---- online softmax over kv for this lane's queries (raw-score max; scale folded into the exp2 fma) ----
-    uint4 pf[QT][4];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      if (kv0 + KV_TILE > nk) {  // ragged last tile of a segment (wave-uniform)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            if (kv >= nk) st[qt][u][r] = -INFINITY;
-          }
-      }
-      float mt = st[qt][0][0];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[qt][u][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mt);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      if (__builtin_amdgcn_ballot_w64(m_new > m_run[qt]) != 0ull) {  // some lane's max moved: rescale (rare after a few tiles)
-        const float alpha = exp2f((m_run[qt] - m_use) * c);  // m_run = -inf -> 0
-        l_run[qt] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < OT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ot[qt][dt][r] *= alpha;
-      }
-      m_run[qt] = m_new;
-      const float mc = -m_use * c;
-      float ps = 0.f;
+    // ---- online softmax over kv for this lane's query (raw-score max; scale folded into the exp2 fma) ----
+    if (kv0 + KV_TILE > nk) {  // ragged last tile of a segment (wave-uniform)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = exp2f(fmaf(st[qt][u][r], c, mc));
-          st[qt][u][r] = pv;
-          ps += pv;
+          const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (kv >= nk) st[u][r] = -INFINITY;
         }
-      ps += __shfl_xor(ps, 32, 64);
-      l_run[qt] += ps;
-      // P^T fragments (B operand) straight from the accumulators
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int tt = u >> 1, hh = u & 1;
-        pf[qt][u].x = pack2<DT>(st[qt][tt][8 * hh + 0], st[qt][tt][8 * hh + 1]);
-        pf[qt][u].y = pack2<DT>(st[qt][tt][8 * hh + 2], st[qt][tt][8 * hh + 3]);
-        pf[qt][u].z = pack2<DT>(st[qt][tt][8 * hh + 4], st[qt][tt][8 * hh + 5]);
-        pf[qt][u].w = pack2<DT>(st[qt][tt][8 * hh + 6], st[qt][tt][8 * hh + 7]);
-      }
     }
-    // ---- O^T += V^T.P^T : each V^T fragment feeds QT MFMAs ----
+    float mt = st[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[u][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {  // some lane's max moved: rescale (rare after a few tiles)
+      const float alpha = exp2f((m_run - m_use) * c);  // m_run = -inf -> 0
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < OT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    const float mc = -m_use * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(fmaf(st[u][r], c, mc));
+        st[u][r] = pv;
+        ps += pv;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run += ps;
+
+    // ---- P^T fragments (B operand) straight from the accumulators ----
+    uint4 pf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = u >> 1, hh = u & 1;
+      pf[u].x = pack2<DT>(st[tt][8 * hh + 0], st[tt][8 * hh + 1]);
+      pf[u].y = pack2<DT>(st[tt][8 * hh + 2], st[tt][8 * hh + 3]);
+      pf[u].z = pack2<DT>(st[tt][8 * hh + 4], st[tt][8 * hh + 5]);
+      pf[u].w = pack2<DT>(st[tt][8 * hh + 6], st[tt][8 * hh + 7]);
+    }
+    // ---- O^T += V^T.P^T ----
 #pragma unroll
     for (int dt = 0; dt < OT; ++dt) {
 #pragma unroll
@@ -216,33 +199,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         const uint16_t* vr = &Vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
         const uint2 lo = *reinterpret_cast<const uint2*>(vr);
         const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
-        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) ot[qt][dt] = HT<DT>::mfma32(vf, pf[qt][u], ot[qt][dt]);
+        ot[dt] = HT<DT>::mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], ot[dt]);
       }
     }
   }
 
   // ---- epilogue: lane (h2, q) holds O^T[d = 32 dt + (r&3) + 8 (r>>2) + 4 h2][q] ----
+  const int qr = q0 + li;
+  if (qr < a.Nq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    uint16_t* op = a.out + ((int64_t)b * a.Nq + qr) * a.ldo + head * D;
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int qr = q0 + 32 * qt + li;
-    if (qr < a.Nq) {
-      const float inv = l_run[qt] > 0.f ? 1.f / l_run[qt] : 0.f;
-      uint16_t* op = a.out + ((int64_t)b * a.Nq + qr) * a.ldo + head * D;
+    for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < OT; ++dt)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int d = 32 * dt + 8 * cc + 4 * h2;
-          if (d < D) {
-            uint2 o;
-            o.x = pack2<DT>(ot[qt][dt][4 * cc + 0] * inv, ot[qt][dt][4 * cc + 1] * inv);
-            o.y = pack2<DT>(ot[qt][dt][4 * cc + 2] * inv, ot[qt][dt][4 * cc + 3] * inv);
-            *reinterpret_cast<uint2*>(op + d) = o;
-          }
+      for (int c = 0; c < 4; ++c) {
+        const int d = 32 * dt + 8 * c + 4 * h2;
+        if (d < D) {
+          uint2 o;
+          o.x = pack2<DT>(ot[dt][4 * c + 0] * inv, ot[dt][4 * c + 1] * inv);
+          o.y = pack2<DT>(ot[dt][4 * c + 2] * inv, ot[dt][4 * c + 3] * inv);
+          *reinterpret_cast<uint2*>(op + d) = o;
         }
-    }
+      }
   }
 }
 
@@ -398,17 +376,9 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldk2 = ldk2; a.ldv2 = ldv2; a.ldo = ldo;
   a.B = B; a.Nq = Nq; a.Nk = Nk; a.Nk2 = Nk2; a.seg2_first_batch = seg2_first_batch; a.heads = heads;
   a.scale_log2 = scale * LOG2E;
-  // two query tiles per wave (K/V fragment reuse) when the head dim leaves the registers for it
-  static const bool force_qt1 = getenv("MIMO_ATTN_QT1") != nullptr;  // tuning knob (A/B runs)
-  const bool qt2 = !force_qt1 && d <= 64 && Nq >= 256;
-  const int qblk = qt2 ? 256 : 128;
-  const dim3 grid((unsigned)((Nq + qblk - 1) / qblk), (unsigned)heads, (unsigned)B);
+  const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
-#define ATTN_LAUNCH(DT, DD)                                                                    \
-  do {                                                                                         \
-    if (qt2 && DD <= 64) hipLaunchKernelGGL((attn_kernel<DT, DD, (DD <= 64 ? 2 : 1)>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((attn_kernel<DT, DD, 1>), grid, dim3(256), 0, st, a);             \
-  } while (0)
+#define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD>), grid, dim3(256), 0, st, a)
   if (dtype == MIMO_F16) {
     switch (d) {
       case 40: ATTN_LAUNCH(MIMO_F16, 40); break;
