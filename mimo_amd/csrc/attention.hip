@@ -22,6 +22,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KV_TILE = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 
+// raw v_exp_f32: arguments are <= 0 here, results below 2^-126 may flush to zero (libm exp2f adds a
+// denormal-range rescale = 4 extra VALU ops per element, which matters in the softmax inner loop)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 struct AttnArgs {
   const uint16_t *q, *k, *v, *k2, *v2;
   uint16_t* out;
@@ -31,7 +35,7 @@ struct AttnArgs {
 };
 
 template <int DT, int D>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
   constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
   constexpr int KP = KS * 16 + 8;          // K tile pitch (halfs): odd multiple of 16 bytes
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const float m_new = fmaxf(m_run, mt);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {  // some lane's max moved: rescale (rare after a few tiles)
-      const float alpha = exp2f((m_run - m_use) * c);  // m_run = -inf -> 0
+      const float alpha = fast_exp2((m_run - m_use) * c);  // m_run = -inf -> 0
       l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < OT; ++dt)
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(fmaf(st[u][r], c, mc));
+        const float pv = fast_exp2(fmaf(st[u][r], c, mc));
         st[u][r] = pv;
         ps += pv;
       }
@@ -236,7 +240,7 @@ struct TAttnArgs {
 };
 
 template <int DT, int D>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void temporal_attn_kernel(const TAttnArgs a) {
   constexpr int KS = (D + 15) / 16;
   constexpr int OT = (D + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TAttnArgs a) {
   float ps = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float p = exp2f(st[r] - mt);
+    const float p = fast_exp2(st[r] - mt);
     st[r] = p;
     ps += p;
   }
@@ -350,13 +354,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int6
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
-  for (int c = threadIdx.x; c < cols; c += 256) s += exp2f(x[c] * scale_log2 - m);
+  for (int c = threadIdx.x; c < cols; c += 256) s += fast_exp2(x[c] * scale_log2 - m);
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
   __syncthreads();
   const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
   for (int c = threadIdx.x; c < cols; c += 256)
-    out[row * ldo + c] = HT<DT>::from_f(exp2f(x[c] * scale_log2 - m) * inv);
+    out[row * ldo + c] = HT<DT>::from_f(fast_exp2(x[c] * scale_log2 - m) * inv);
 }
 
 }  // namespace
