@@ -2,23 +2,28 @@
 // either a dense GEMM  out[M,N] = A[M,K].W[N,K]^T  or a channels-last implicit-GEMM
 // convolution (3x3 / 1x1, stride 1|2, optional nearest-upsample gather, optional extra 1x1
 // tap over a second tensor = fused ResBlock shortcut), with a fused epilogue
-// (bias, per-image bias = time embedding / collapsed cross-attention, SiLU, GEGLU,
+// (bias, per-batch bias = time embedding / collapsed cross-attention, SiLU, GEGLU,
 // residual add, fp32|half store).
 //
 // Reference ops replaced: see include/mimo_hip.h (mimo_gemm / mimo_conv2d).
 //
-// Tiling (gfx950): block = 256 threads = 4 waves (2 x 2); block tile 128 x (32*NR) x 64;
-// each wave owns 64 x (16*NR) as 4 x NR MFMA 16x16x32 tiles, fp32 accumulators in
-// registers.  Operands are staged global -> LDS by DMA (16-byte chunks, XOR-swizzled on the source side so
-// the ds_read_b128 fragment reads are bank-conflict-free), double-buffered with one
-// barrier per K-tile; the next tile's global->LDS DMA (buffer_load ... lds) is in flight under the MFMAs.
+// Tiling (gfx950): block = 2*WM waves laid out WM x 2; block tile (64*WM) x (32*NR) x 64;
+// each wave owns 64 x (16*NR) as 4 x NR MFMA 16x16x32 tiles, fp32 accumulators in VGPRs.
+// Operands go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`): hardware range checking
+// turns padding taps / ragged edges into zero fill, the XOR swizzle that makes the
+// ds_read_b128 fragment reads bank-conflict-free is applied on the SOURCE address (the DMA
+// writes lane-linear), and an NSTAGE-deep LDS ring keeps NSTAGE-1 K-tiles in flight under
+// the MFMAs with ONE barrier and one counted `s_waitcnt vmcnt` per K-tile.
+//   WM = 2, NSTAGE = 2 (128-row tile, 72-80 KB LDS, 2 blocks/CU): small / skinny problems
+//   WM = 4, NSTAGE = 3 (256-row tile, 144-159 KB LDS, 1 block/CU): large-M problems
 // The MFMA is issued "swapped" (W fragment as the A operand) so that every lane ends up
 // with 4 consecutive output columns of one row -> 16-byte epilogue loads/stores.
+#include <stdlib.h>
+
 #include "common.cuh"
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 
 struct GemmArgs {
@@ -41,16 +46,28 @@ struct GemmArgs {
   int chunks1, chunks2, nkt;
 };
 
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
-template <int DT, int NR, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+template <int DT, int NR, int MODE, int WM, int NSTAGE>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
+  constexpr int THREADS = 128 * WM;
+  constexpr int BM = 64 * WM;
   constexpr int BN = 32 * NR;
-  constexpr int NRB = BN / 32;  // B rows staged per thread
-  // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt(0) before every fragment read while a
-  // DMA is in flight): [A buf0 | A buf1 | B buf0 | B buf1], 16-byte units
-  __shared__ __attribute__((aligned(16))) uint4 smem[2 * BM * 8 + 2 * BN * 8];
-  constexpr int A_OFF = 0, B_OFF = 2 * BM * 8;
+  constexpr int PASS = 16 * WM;                       // tile rows covered by one DMA pass of the whole block
+  constexpr int NBJ = (BN + PASS - 1) / PASS;         // B passes
+  constexpr int BNA = NBJ * PASS > BN ? BN + 8 : BN;  // + 8 dummy rows that absorb the surplus (all-zero) DMAs
+  constexpr int LOADS = 4 + NBJ;                      // DMAs per thread per K-tile
+  constexpr int STAGE = (BM + BNA) * 8;               // 16-byte units per ring slot: [A tile | B tile]
+  // ONE LDS object (a second __shared__ array would make hipcc drain vmcnt before fragment reads)
+  __shared__ __attribute__((aligned(16))) uint4 smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,25 +81,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const int64_t M0 = (int64_t)tile_m * BM;
   const int N0 = tile_n * BN;
 
-  // ---- staging roles: thread -> (row srow + 32 j, 16-byte chunk sc) ----
-  // LDS-DMA writes lane-linear (wave-uniform base + lane*16), so the XOR swizzle that makes the fragment
-  // reads conflict-free is applied to the SOURCE: the lane that fills physical chunk (tid&7) of row srow+32j
-  // fetches logical chunk sc = (tid&7) ^ (row&7).
+  // ---- staging roles: thread -> (row srow + PASS*j, physical 16-byte chunk tid&7) ----
+  // The DMA writes lane-linear (wave-uniform base + lane*16), so the lane that fills physical chunk (tid&7) of
+  // a row fetches logical chunk sc = (tid&7) ^ (row&7); (srow + PASS*j) & 7 == srow & 7.
   const int srow = tid >> 3;
-  const int sc = (tid & 7) ^ (srow & 7);  // (srow + 32 j) & 7 == srow & 7
+  const int sc = (tid & 7) ^ (srow & 7);
+  constexpr unsigned OOB = 0xFFFFFFF0u;  // out of every descriptor's range -> the DMA writes zeros
 
-  // Operands are read through buffer descriptors: a 32-bit byte offset per lane and hardware range checking,
-  // so padding taps / ragged edges simply use an out-of-range offset and read zeros (no branches, no selects:
-  // all loads of a tile issue back-to-back and stay in flight under the MFMAs of the current tile).
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-
-  unsigned a_base[4];  // MODE 0: byte offset of (row, chunk 0); 1: byte offset of tap (0,0); 2: image index
+  unsigned a_base[4];  // MODE 0: byte offset of (row, chunk sc); 1: byte offset of tap (0,0); 2: image index
   unsigned a2_base[4];
   int a_iy0[4], a_ix0[4];
   bool a_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int64_t m = M0 + srow + 32 * j;
+    const int64_t m = M0 + srow + PASS * j;
     a_ok[j] = m < g.M;
     a2_base[j] = 0;
     if (CONV) {
@@ -100,16 +112,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       a_iy0[j] = a_ix0[j] = 0;
     }
   }
-  unsigned b_base[NRB];
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned b_base[NBJ];
+  unsigned b_row0[NBJ];  // first tile row (wave-uniform) of this wave's 8-row DMA in pass j
 #pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const int n = N0 + srow + 32 * j;
-    b_base[j] = n < g.N ? (unsigned)(((int64_t)n * g.ldw + sc * 8) * 2) : OOB;
+  for (int j = 0; j < NBJ; ++j) {
+    const int r = srow + PASS * j;
+    const int n = N0 + r;
+    b_base[j] = (r < BN && n < g.N) ? (unsigned)(((int64_t)n * g.ldw + sc * 8) * 2) : OOB;
+    const unsigned r0 = 8 * wave_u + PASS * j;
+    b_row0[j] = r0 < (unsigned)BN ? r0 : (unsigned)BN;  // surplus passes land in the dummy rows
   }
 
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  // raw buffer descriptor: base, stride 0, num_records (bytes), flags — the same words the builtin builds
+  // raw buffer descriptor: base, stride 0, num_records (bytes), flags
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
     i32x4 r;
@@ -118,22 +133,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   };
   // One DMA = 64 lanes x 16 B = 8 tile rows; lane l lands at lds_base + 16 l.  Issued through inline asm so that
   // hipcc does NOT track it: with the builtin it drains vmcnt(0) before the first fragment read of every tile
-  // (it cannot prove the reads touch the other buffer), which serialises DMA and MFMA.  The kernel waits for
-  // its DMAs itself (s_waitcnt vmcnt(0) right before the end-of-tile barrier).  M0 is saved/restored.
+  // (it cannot prove the reads touch another ring slot), which serialises DMA and MFMA.  The kernel counts its
+  // DMAs itself (s_waitcnt vmcnt below).  M0 is saved/restored.
   auto dma = [&](const i32x4& r, unsigned off, unsigned lds_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(r), "s"(lds_base) : "memory");
   };
   const i32x4 rW = make_rsrc(g.W, g.w_bytes);
-  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
-  auto load_tile = [&](int kt, int buf) {
-    // offsets are computed on (uniform) branches; the loads themselves are issued once, after the join, so no
-    // PHI copy of a loaded value can pull a vmcnt wait in front of the MFMAs
-    unsigned offA[4], kw;
-    bool cok;
+
+  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform)
+  auto load_tile = [&](int kt, int slot) {
+    // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
+    unsigned offA[4], kw = 0;
+    bool cok = false;
     bool main_tap = true;
+    const bool live = kt < g.nkt;
     if (CONV) {
       const int ntap_tiles = g.ks * g.ks * g.chunks1;
       main_tap = kt < ntap_tiles;
@@ -162,46 +178,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         kw = (unsigned)(((int64_t)tap * g.Cin + c0) * 2);
       } else {
         const int c0 = (kt - ntap_tiles) * BK;
-        cok = c0 + sc * 8 < g.Cin2;
+        cok = live & (c0 + sc * 8 < g.Cin2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a2_base[j] + (unsigned)(c0 * 2) : OOB;
         kw = (unsigned)(((int64_t)g.ks * g.ks * g.Cin + c0) * 2);
       }
     } else {
-      cok = kt * BK + sc * 8 < g.K;
+      cok = live & (kt * BK + sc * 8 < g.K);
       kw = (unsigned)(kt * BK * 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
     const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
+    const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], smem_base + 16u * (A_OFF + buf * (BM * 8) + (wave_u * 8 + 32 * j) * 8));
+    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
 #pragma unroll
-    for (int j = 0; j < NRB; ++j)
-      dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, smem_base + 16u * (B_OFF + buf * (BN * 8) + (wave_u * 8 + 32 * j) * 8));
+    for (int j = 0; j < NBJ; ++j)
+      dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
   };
+
   f32x4 acc[NR][4];
 #pragma unroll
   for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = g.nkt;
-  load_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // buffer 0 published
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1, buf ^ 1);  // DMA into the other buffer flies under this tile's MFMAs
+  auto compute = [&](auto slot_c) {
+    constexpr int S = decltype(slot_c)::value;
+    const uint4* sa = &smem[S * STAGE];
+    const uint4* sb = &smem[S * STAGE + BM * 8];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ch = (4 * s + lg) ^ (li & 7);
       uint4 fa[4], fb[NR];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = smem[A_OFF + buf * (BM * 8) + (wm * 64 + mi * 16 + li) * 8 + ch];
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = sa[(wm * 64 + mi * 16 + li) * 8 + ch];
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni) fb[ni] = smem[B_OFF + buf * (BN * 8) + (wn * 16 * NR + ni * 16 + li) * 8 + ch];
+      for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
@@ -209,9 +223,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
           acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of the next tile have landed
-    __syncthreads();                                  // ... everyone's have, and every wave is done reading `buf`
+  };
+
+  // One K-tile: wait until everything but the newest NSTAGE-2 tiles of THIS wave has landed, barrier (all
+  // waves' parts landed AND every wave is done reading the slot about to be recycled), refill that slot with
+  // tile kt + NSTAGE - 1, then run the MFMAs of tile kt while the DMAs fly.
+  auto step = [&](auto slot_c, int kt) {
+    constexpr int S = decltype(slot_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+    __syncthreads();
+    load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
+    compute(slot_c);
+  };
+
+  const int nkt = g.nkt;
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i) load_tile(i, i);
+  for (int kt = 0; kt < nkt; kt += NSTAGE) {
+    step(IC<0>{}, kt);
+    if (kt + 1 < nkt) step(IC<1 % NSTAGE>{}, kt + 1);
+    if (NSTAGE > 2 && kt + 2 < nkt) step(IC<2 % NSTAGE>{}, kt + 2);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 
   // ---- epilogue: lane holds out[m = .. + li][n = .. + 4*lg + r], r = 0..3 ----
   const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
@@ -280,23 +313,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   }
 }
 
+template <int DT, int MODE, int NR>
+int launch_nr(GemmArgs& g, hipStream_t st) {
+  constexpr int BN = 32 * NR;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  // 256-row tiles + 3-deep ring once the grid still fills the chip at one block per CU; MIMO_GEMM_CFG=1|2 forces
+  // the small / large configuration (tuning knob for A/B runs)
+  static const int forced = getenv("MIMO_GEMM_CFG") ? atoi(getenv("MIMO_GEMM_CFG")) : 0;
+  const int64_t big_tiles = ((g.M + 255) / 256) * g.tiles_n;
+  const bool big = forced == 2 || (forced == 0 && big_tiles >= 512);
+  if (big) {
+    const int64_t nwg = big_tiles;
+    if (nwg > 0x7fffffff) return MIMO_EINVAL;
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 3>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+  } else {
+    const int64_t nwg = ((g.M + 127) / 128) * g.tiles_n;
+    if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+  }
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
 template <int DT, int MODE>
 int launch(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
   // NR = 5 (BN = 160) divides every SD1.5 width (320/640/960/1280/1920/2560); NR = 4 otherwise
-  const bool use5 = !geglu && (g.N % 160 == 0);
-  const int BN = use5 ? 160 : 128;
-  const int64_t tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
-  const int64_t nwg = tiles_m * g.tiles_n;
-  if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-  if (use5)
-    hipLaunchKernelGGL((gemm_kernel<DT, 5, MODE>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_kernel<DT, 4, MODE>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-  MIMO_LAUNCH_CHECK();
-  return MIMO_OK;
+  if (!geglu && (g.N % 160 == 0)) return launch_nr<DT, MODE, 5>(g, st);
+  return launch_nr<DT, MODE, 4>(g, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -357,16 +402,16 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.chunks1 = (p->Cin + BK - 1) / BK;
   g.chunks2 = (p->Cin2 + BK - 1) / BK;
   g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
-  hipStream_t st = (hipStream_t)stream;
   {
     const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
     if (ab >= 0xFFFFFFF0LL || a2b >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;
     g.a_bytes = (unsigned)ab; g.a2_bytes = (unsigned)a2b; g.w_bytes = (unsigned)wb;
   }
   const bool ups = p->Hup > 0;
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == MIMO_F16) return ups ? launch<MIMO_F16, 2>(g, st) : launch<MIMO_F16, 1>(g, st);
   if (dtype == MIMO_BF16) return ups ? launch<MIMO_BF16, 2>(g, st) : launch<MIMO_BF16, 1>(g, st);
   return MIMO_EDTYPE;
 }
 
-extern "C" int mimo_version(void) { return 1; }
+extern "C" int mimo_version(void) { return 2; }
