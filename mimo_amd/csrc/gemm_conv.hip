@@ -140,7 +140,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
     // M0 = LDS base; hipcc never uses M0 in this kernel (LDS ops need none on gfx9+), so it is not saved
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :: "v"(voff), "s"(r), "s"(lds_base), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+                 :: "v"(voff), "s"(r), "s"(lds_base), "s"(soff) : "memory");
   };
   const i32x4 rW = make_rsrc(g.W, g.w_bytes);
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
@@ -219,10 +219,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < NBJ; ++j) offB[j] = vb[j];
       }
     }
-    i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
-    // wave-uniform by construction; make it provable so the descriptor lives in SGPRs
-    rsel.x = __builtin_amdgcn_readfirstlane(rsel.x); rsel.y = __builtin_amdgcn_readfirstlane(rsel.y);
-    rsel.z = __builtin_amdgcn_readfirstlane(rsel.z); rsel.w = __builtin_amdgcn_readfirstlane(rsel.w);
+    const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
     const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma(rsel, offA[j], soffA, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
