@@ -35,7 +35,7 @@ struct GemmArgs {
   const float* img_bias;
   const void* res;
   int64_t lda, ldw, ldo, ldr, M, rows_per_img, ldib;
-  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor extents (each operand < 2 GiB)
+  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor extents (each operand < 4 GiB)
   int N, K;
   float out_scale;
   unsigned flags;
@@ -86,9 +86,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   // a row fetches logical chunk sc = (tid&7) ^ (row&7); (srow + PASS*j) & 7 == srow & 7.
   const int srow = tid >> 3;
   const int sc = (tid & 7) ^ (srow & 7);
-  // out of every descriptor's range (extents are < 2 GiB) even after a < 2 GiB soffset is added, without
-  // 32-bit wrap-around -> the DMA writes zeros
-  constexpr unsigned OOB = 0x80000000u;
+  constexpr unsigned OOB = 0xFFFFFFF0u;  // out of every descriptor's range -> the DMA writes zeros
 
   unsigned a_base[4];  // MODE 0: byte offset of (row, chunk sc); 1: byte offset of tap (0,0); 2: image index
   unsigned a2_base[4];
@@ -137,42 +135,29 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   // hipcc does NOT track it: with the builtin it drains vmcnt(0) before the first fragment read of every tile
   // (it cannot prove the reads touch another ring slot), which serialises DMA and MFMA.  The kernel counts its
   // DMAs itself (s_waitcnt vmcnt below).  M0 is saved/restored.
-  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
-    // M0 = LDS base; hipcc never uses M0 in this kernel (LDS ops need none on gfx9+), so it is not saved
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :: "v"(voff), "s"(r), "s"(lds_base), "s"(soff) : "memory");
+  auto dma = [&](const i32x4& r, unsigned off, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(r), "s"(lds_base) : "memory");
   };
   const i32x4 rW = make_rsrc(g.W, g.w_bytes);
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
 
-  // loop-invariant voffsets: rows / columns outside the problem are permanently out of range
-  unsigned va[4], vb[NBJ];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) va[j] = a_ok[j] ? (CONV ? a2_base[j] : a_base[j]) : OOB;
-#pragma unroll
-  for (int j = 0; j < NBJ; ++j) vb[j] = b_base[j];
-  const bool ktail = (g.K & (BK - 1)) != 0;  // dense: last K-tile is partial
-  // conv: (tap, channel-chunk) of the NEXT tile to be issued; tiles are issued in order, so no division per tile
-  int cur_tap = 0, cur_cc = 0;
-
-  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform).
-  // The per-lane voffset is loop-invariant wherever possible; the K position travels in the scalar soffset.
+  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform)
   auto load_tile = [&](int kt, int slot) {
-    unsigned offA[4], offB[NBJ], soffA = 0, soffB = 0;
+    // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
+    unsigned offA[4], kw = 0;
+    bool cok = false;
     bool main_tap = true;
     const bool live = kt < g.nkt;
-    if (!live) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) offA[j] = OOB;
-#pragma unroll
-      for (int j = 0; j < NBJ; ++j) offB[j] = OOB;
-    } else if (CONV) {
-      const int ntaps = g.ks * g.ks;
-      main_tap = cur_tap < ntaps;
-      const int c0 = cur_cc * BK;
+    if (CONV) {
+      const int ntap_tiles = g.ks * g.ks * g.chunks1;
+      main_tap = kt < ntap_tiles;
       if (main_tap) {
-        const int ky = cur_tap / g.ks, kx = cur_tap - ky * g.ks;
-        const bool cok = c0 + sc * 8 < g.Cin;
+        const int tap = kt / g.chunks1;
+        const int c0 = (kt - tap * g.chunks1) * BK;
+        const int ky = tap / g.ks, kx = tap - ky * g.ks;
+        cok = c0 + sc * 8 < g.Cin;
         const int Hv = MODE == 2 ? g.Hup : g.Hin;
         const int Wv = MODE == 2 ? g.Wup : g.Win;
         const unsigned tap_off = (unsigned)((((int64_t)ky * g.Win + kx) * g.Cin + c0) * 2);
@@ -186,45 +171,31 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
             const int sx = min((int)floorf((float)vx * g.sw), g.Win - 1);
             off = (unsigned)(((((int64_t)a_base[j] * g.Hin + sy) * g.Win + sx) * g.Cin + c0 + sc * 8) * 2);
           } else {
-            off = a_base[j] + tap_off;  // 32-bit wrap-around add: a_base may be "negative" on the border
+            off = a_base[j] + tap_off;
           }
           offA[j] = ok ? off : OOB;
         }
-        soffB = (unsigned)(((int64_t)cur_tap * g.Cin + c0) * 2);
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) offB[j] = cok ? vb[j] : OOB;
-        if (++cur_cc == g.chunks1) { cur_cc = 0; ++cur_tap; }
+        kw = (unsigned)(((int64_t)tap * g.Cin + c0) * 2);
       } else {
-        const bool cok = c0 + sc * 8 < g.Cin2;
-        soffA = (unsigned)(c0 * 2);
+        const int c0 = (kt - ntap_tiles) * BK;
+        cok = live & (c0 + sc * 8 < g.Cin2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) offA[j] = cok ? va[j] : OOB;
-        soffB = (unsigned)(((int64_t)ntaps * g.Cin + c0) * 2);
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) offB[j] = cok ? vb[j] : OOB;
-        ++cur_cc;
+        for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a2_base[j] + (unsigned)(c0 * 2) : OOB;
+        kw = (unsigned)(((int64_t)g.ks * g.ks * g.Cin + c0) * 2);
       }
     } else {
-      soffA = soffB = (unsigned)(kt * BK * 2);
-      if (ktail && kt == g.nkt - 1) {
-        const bool cok = kt * BK + sc * 8 < g.K;
+      cok = live & (kt * BK + sc * 8 < g.K);
+      kw = (unsigned)(kt * BK * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) offA[j] = cok ? va[j] : OOB;
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) offB[j] = cok ? vb[j] : OOB;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) offA[j] = va[j];
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) offB[j] = vb[j];
-      }
+      for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
     const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
     const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], soffA, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
+    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
 #pragma unroll
-    for (int j = 0; j < NBJ; ++j) dma(rW, offB[j], soffB, slot_base + 16u * ((BM + b_row0[j]) * 8));
+    for (int j = 0; j < NBJ; ++j)
+      dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
   };
 
   f32x4 acc[NR][4];
@@ -237,25 +208,21 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int S = decltype(slot_c)::value;
     const uint4* sa = &smem[S * STAGE];
     const uint4* sb = &smem[S * STAGE + BM * 8];
-    // all 2 x (4 + NR) fragment reads of the tile are issued up-front: the second k-step's reads land under the
-    // first k-step's MFMAs (one LDS-latency bubble per tile instead of two)
-    uint4 fa[2][4], fb[2][NR];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ch = (4 * s + lg) ^ (li & 7);
+      uint4 fa[4], fb[NR];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[s][mi] = sa[(wm * 64 + mi * 16 + li) * 8 + ch];
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = sa[(wm * 64 + mi * 16 + li) * 8 + ch];
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni) fb[s][ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
           // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
-          acc[ni][mi] = HT<DT>::mfma16(fb[s][ni], fa[s][mi], acc[ni][mi]);
+          acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
+    }
   };
 
   // One K-tile: wait until everything but the newest NSTAGE-2 tiles of THIS wave has landed, barrier (all
@@ -399,7 +366,7 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
   g.nkt = (K + BK - 1) / BK;
   const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
-  if (ab >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // operands are addressed with 31-bit offsets
+  if (ab >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;  // operands are addressed with 32-bit offsets
   g.a_bytes = (unsigned)ab; g.a2_bytes = 0; g.w_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIMO_F16) return launch<MIMO_F16, 0>(g, st);
@@ -437,7 +404,7 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
   {
     const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
-    if (ab >= 0x80000000LL || a2b >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;
+    if (ab >= 0xFFFFFFF0LL || a2b >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;
     g.a_bytes = (unsigned)ab; g.a2_bytes = (unsigned)a2b; g.w_bytes = (unsigned)wb;
   }
   const bool ups = p->Hup > 0;
