@@ -321,7 +321,9 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   // the small / large configuration (tuning knob for A/B runs)
   static const int forced = getenv("MIMO_GEMM_CFG") ? atoi(getenv("MIMO_GEMM_CFG")) : 0;
   const int64_t big_tiles = ((g.M + 255) / 256) * g.tiles_n;
-  const bool big = forced == 2 || (forced == 0 && big_tiles >= 512);
+  // measured (tools/microbench.py): the 256-row ring wins for the wide GEGLU GEMMs (NR = 4, N >= 2560: +4..10 %)
+  // and loses up to 11 % on the NR = 5 shapes, so it is selected for NR = 4 only
+  const bool big = forced == 2 || (forced == 0 && NR == 4 && big_tiles >= 512);
   if (big) {
     const int64_t nwg = big_tiles;
     if (nwg > 0x7fffffff) return MIMO_EINVAL;
