@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--shard-windows", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch the denoising forward eagerly instead of as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=float, default=0.0, help=argparse.SUPPRESS)  # child mode: clip FLOPs
     a = ap.parse_args()
@@ -197,6 +198,7 @@ def main():
     pipe = build_pipeline(dev, dtype)
     frames = a.frames * (world if a.shard_windows else 1)
     pipe.shard_windows = a.shard_windows and world > 1
+    pipe.use_graphs = not a.no_graphs and not pipe.shard_windows
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
 
     def clip():

@@ -260,18 +260,23 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(const TAttnArgs a
   f32x16 st;
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[r] = 0.f;
+  // every global read goes through a buffer descriptor: frames >= F / channels >= D use an out-of-range offset
+  // and read zeros, so all loads issue back-to-back without branches
+  const int64_t tot_rows = (int64_t)a.b * F * a.HW;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (int)(tot_rows * a.ldq * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.k, 0, (int)(tot_rows * a.ldk * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.v, 0, (int)(tot_rows * a.ldv * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   {
     const bool fok = li < F;
     const int64_t row = row0 + (int64_t)li * a.HW;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int kk = 16 * s + 8 * h2;
-      uint4 kf = make_uint4(0, 0, 0, 0), qf = make_uint4(0, 0, 0, 0);
-      if (fok && kk < D) {
-        kf = *reinterpret_cast<const uint4*>(a.k + row * a.ldk + head * D + kk);
-        qf = *reinterpret_cast<const uint4*>(a.q + row * a.ldq + head * D + kk);
-      }
-      st = HT<DT>::mfma32(kf, qf, st);
+      const bool ok = fok & (kk < D);
+      const u32x4 kv4 = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (unsigned)((row * a.ldk + head * D + kk) * 2) : OOB, 0, 0);
+      const u32x4 qv4 = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)((row * a.ldq + head * D + kk) * 2) : OOB, 0, 0);
+      st = HT<DT>::mfma32(make_uint4(kv4.x, kv4.y, kv4.z, kv4.w), make_uint4(qv4.x, qv4.y, qv4.z, qv4.w), st);
     }
   }
   float mt = -INFINITY;
@@ -309,10 +314,13 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(const TAttnArgs a
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       uint16_t e[8];
+      // lane part of the address in the voffset, (compile-time) frame part in the scalar soffset
+      const unsigned vlane = (unsigned)(((row0 + (int64_t)(4 * h2) * a.HW) * a.ldv + head * D + d) * 2);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int f = 16 * u + 4 * h2 + (j & 3) + 8 * (j >> 2);
-        e[j] = (d < D && f < F) ? a.v[(row0 + (int64_t)f * a.HW) * a.ldv + head * D + d] : (uint16_t)0;
+        const int fu = 16 * u + (j & 3) + 8 * (j >> 2);  // frame = fu + 4 h2
+        const bool ok = (d < D) & (fu + 4 * h2 < F);
+        e[j] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rv, ok ? vlane : OOB, (unsigned)((int64_t)fu * a.HW * a.ldv * 2), 0);
       }
       uint4 vf;
       vf.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);

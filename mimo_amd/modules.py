@@ -251,7 +251,15 @@ class SpatialTransformerBlock(HipModule):
         """bank: half [1, Nb, C] (the cond reference features).  Projects K/V once (step- and frame-invariant)."""
         p = self.packed(dtype)
         self.bank = [bank]
-        self.bank_kv = ops.gemm(bank.reshape(-1, self.dim).to(dtype).contiguous(), p["kv"])
+        kv = ops.gemm(bank.reshape(-1, self.dim).to(dtype).contiguous(), p["kv"])
+        # keep ONE persistent buffer per block: a captured hipGraph of the denoising forward reads it by address,
+        # so a new clip refreshes its contents instead of re-capturing
+        buf = self.__dict__.get("_bank_kv_buf")
+        if buf is not None and buf.shape == kv.shape and buf.dtype == kv.dtype and buf.device == kv.device:
+            buf.copy_(kv)
+        else:
+            self.__dict__["_bank_kv_buf"] = buf = kv
+        self.bank_kv = buf
 
 
 class SpatialTransformer(HipModule):

@@ -65,6 +65,42 @@ def exchange_predictions(my_preds, units, rank, world, group=None):
     return out
 
 
+class GraphedDenoiser:
+    """The denoising-UNet forward for one (batch, window, latent) shape captured as ONE hipGraph (torch.cuda.CUDAGraph
+    over the C-ABI launches, which all go to the capture stream): ~430 kernel launches and the host-side dispatch
+    collapse into a single replay.  Inputs live in static buffers; the bank K/V tensors are persistent per block."""
+
+    def __init__(self, unet, b, F, h, w, c0, dtype):
+        dev = unet.device
+        self.unet, self.b, self.F = unet, b, F
+        self.x = torch.zeros((b * F, h, w, 8), device=dev, dtype=dtype)
+        self.pose = torch.zeros((b * F, h, w, c0), device=dev, dtype=torch.float32)
+        self.t = torch.zeros((1,), device=dev, dtype=torch.float32)
+        self.ehs = torch.zeros((b, 1, unet.cross_dim), device=dev, dtype=torch.float32)
+        self.graph = None
+        self.out = None
+
+    def capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside capture: weight packing, lazy library load
+            self.unet.run_tokens(self.x, self.t, self.ehs, self.b, self.F, self.pose)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self.unet.run_tokens(self.x, self.t, self.ehs, self.b, self.F, self.pose)
+
+    def __call__(self, x, t, ehs, pose):
+        self.x.copy_(x)
+        self.pose.copy_(pose)
+        self.t.fill_(float(t))
+        self.ehs.copy_(ehs)
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.out
+
+
 class Pose2VideoPipeline:
     def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
                  image_proj_model=None, tokenizer=None, text_encoder=None):
@@ -75,6 +111,8 @@ class Pose2VideoPipeline:
         self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
+        self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
+        self._graphs = {}
         self._clip_processor = None
 
     def to(self, device=None, dtype=None):
@@ -175,8 +213,14 @@ class Pose2VideoPipeline:
                     lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)                   # [Fw,h,w,4]
                     x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
                     rep = 2 if cfg else 1
-                    pred = unet.run_tokens(x.repeat(rep, 1, 1, 1), t, ehs, rep, idx.numel(),
-                                           win_pose[wi].repeat(rep, 1, 1, 1))
+                    if self.use_graphs:
+                        key = (rep, idx.numel(), h, w, dt)
+                        if key not in self._graphs:
+                            self._graphs[key] = GraphedDenoiser(unet, rep, idx.numel(), h, w, pose_tok.shape[-1], dt)
+                        pred = self._graphs[key](x.repeat(rep, 1, 1, 1), t, ehs, win_pose[wi].repeat(rep, 1, 1, 1))
+                    else:
+                        pred = unet.run_tokens(x.repeat(rep, 1, 1, 1), t, ehs, rep, idx.numel(),
+                                               win_pose[wi].repeat(rep, 1, 1, 1))
                     ops.window_accumulate(pred, idx, acc, counter)
             else:
                 for (wi, half) in my_units:

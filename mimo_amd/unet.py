@@ -138,6 +138,7 @@ class UNetBase(HipModule):
         self.with_out, self.groups, self.eps = with_out, g, eps
         self.in_channels, self.out_channels, self.boc = in_channels, out_channels, boc
         self.num_upsamplers = len(boc) - 1
+        self.cross_dim = cross_attention_dim
         self.compute_dtype = torch.float16
         # column slices into the per-forward fused time-embedding / cross-attention matrices
         off = 0
@@ -198,7 +199,10 @@ class UNetBase(HipModule):
         """Timesteps(flip_sin_to_cos, shift 0) -> TimestepEmbedding -> silu -> ALL 22 time_emb_proj in one GEMM;
         ALL 16 collapsed cross-attentions in one GEMM (src/models/unet_3d_edit_bkfill.py:447-468, resnet.py:226)."""
         dev = self.device
-        t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(ctx.b)
+        if torch.is_tensor(timestep) and timestep.device == dev:
+            t = timestep.reshape(-1).float().expand(ctx.b)  # device scalar: capturable in a hipGraph
+        else:
+            t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(ctx.b)
         ang = t[:, None] * p["freqs"][None, :]
         t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ctx.dtype)  # [b, 320] (host-side glue, b x 320)
         e1 = ops.gemm(t_emb, p["t1_w"], bias=p["t1_b"], silu=True)
