@@ -220,6 +220,11 @@ def main():
     if a.warmup == 0 and rank == 0:
         clip_flops = clip_launches = 0
     barrier()
+    if rank == 0:
+        pipe.stage_times = {}
+        clip()  # one extra untimed clip with per-stage HIP-event marks
+        stage_ms, pipe.stage_times = pipe.stage_times, None
+    barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         video = clip()
@@ -244,7 +249,8 @@ def main():
                                    + ("one long clip, (window x CFG-half) units sharded, all_gather per step" if a.shard_windows
                                       else "independent clip per GPU, no collective"),
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),
-                       "kernel_launches_per_clip": clip_launches},
+                       "kernel_launches_per_clip": clip_launches,
+                       "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs)},
             "roofline": {"bound": "mfma", "kernel": "denoising_unet forward (2x24 latent frames 64x64): gemm_kernel (implicit-GEMM conv / "
                                   "linear) + attn_kernel dominate", "achieved": fwd_flops / t_fwd / 1e12, "peak": PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": fwd_flops / t_fwd / 1e12 / PEAK_TFLOPS, "traffic": None,

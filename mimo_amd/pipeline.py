@@ -87,8 +87,10 @@ class GraphedDenoiser:
             self.unet.run_tokens(self.x, self.t, self.ehs, self.b, self.F, self.pose)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        saved, ops.COUNTER = ops.COUNTER, {"flops": 0, "launches": 0}
         with torch.cuda.graph(self.graph):
             self.out = self.unet.run_tokens(self.x, self.t, self.ehs, self.b, self.F, self.pose)
+        self.work, ops.COUNTER = ops.COUNTER, saved  # algorithmic FLOPs / launches replayed by every graph launch
 
     def __call__(self, x, t, ehs, pose):
         self.x.copy_(x)
@@ -98,6 +100,9 @@ class GraphedDenoiser:
         if self.graph is None:
             self.capture()
         self.graph.replay()
+        if ops.COUNTER is not None:
+            ops.COUNTER["flops"] += self.work["flops"]
+            ops.COUNTER["launches"] += self.work["launches"]
         return self.out
 
 
@@ -112,6 +117,7 @@ class Pose2VideoPipeline:
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
         self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
+        self.stage_times = None     # dict -> accumulates per-stage milliseconds (HIP events) of run_tensors
         self._graphs = {}
         self._clip_processor = None
 
@@ -174,6 +180,15 @@ class Pose2VideoPipeline:
         ehs = torch.cat([torch.zeros_like(ehs_c), ehs_c], 0) if cfg else ehs_c
 
         # VAE encode: reference image + F background frames; pose guider
+        marks = []  # (stage name, event) pairs when self.stage_times is a dict (bench instrumentation)
+
+        def mark(name):
+            if self.stage_times is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
+
+        mark("start")
         ref_lat = self._encode_frames(ref_image.to(dev).float())               # [1,h,w,4]
         bk_tok = self._encode_frames(bk_images.to(dev).float()).to(dt)         # [F,h,w,4]
         pose_in = ops.ncfhw_to_tokens(pose_images.to(dev).float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
@@ -194,6 +209,7 @@ class Pose2VideoPipeline:
         except EarlyExit:
             pass
         reader.update(writer)
+        mark("vae_encode+pose_guider+reference_unet")
 
         windows = get_context_scheduler(context_schedule)(0, num_inference_steps, F, context_frames, context_stride,
                                                           context_overlap)
@@ -240,9 +256,15 @@ class Pose2VideoPipeline:
                 callback(step, t, latents)
         reader.clear()
         writer.clear()
+        mark("denoising_loop")
         if not decode:
             return latents
         video = self._decode_frames(latents)
+        mark("vae_decode")
+        if self.stage_times is not None:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                self.stage_times[n1] = self.stage_times.get(n1, 0.0) + e0.elapsed_time(e1)
         return (video, latents) if return_latents else video
 
     def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond):
