@@ -55,16 +55,18 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
-template <int DT, int NR, int MODE, int WM, int NSTAGE>
-__global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
+template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
-  constexpr int THREADS = 128 * WM;
+  constexpr int THREADS = 64 * WM * WN;
   constexpr int BM = 64 * WM;
-  constexpr int BN = 32 * NR;
-  constexpr int PASS = 16 * WM;                       // tile rows covered by one DMA pass of the whole block
+  constexpr int BN = 16 * NR * WN;
+  constexpr int PASS = THREADS / 8;                   // tile rows covered by one DMA pass of the whole block
+  constexpr int NAJ = BM / PASS;                      // A passes
   constexpr int NBJ = (BN + PASS - 1) / PASS;         // B passes
   constexpr int BNA = NBJ * PASS > BN ? BN + 8 : BN;  // + 8 dummy rows that absorb the surplus (all-zero) DMAs
-  constexpr int LOADS = 4 + NBJ;                      // DMAs per thread per K-tile
+  constexpr int LOADS = NAJ + NBJ;                    // DMAs per thread per K-tile
+  static_assert(BM % PASS == 0, "A tile must be a whole number of DMA passes");
   constexpr int STAGE = (BM + BNA) * 8;               // 16-byte units per ring slot: [A tile | B tile]
   // ONE LDS object (a second __shared__ array would make hipcc drain vmcnt before fragment reads)
   __shared__ __attribute__((aligned(16))) uint4 smem[NSTAGE * STAGE];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int lg = lane >> 4, li = lane & 15;
 
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
@@ -88,12 +90,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   const int sc = (tid & 7) ^ (srow & 7);
   constexpr unsigned OOB = 0xFFFFFFF0u;  // out of every descriptor's range -> the DMA writes zeros
 
-  unsigned a_base[4];  // MODE 0: byte offset of (row, chunk sc); 1: byte offset of tap (0,0); 2: image index
-  unsigned a2_base[4];
-  int a_iy0[4], a_ix0[4];
-  bool a_ok[4];
+  unsigned a_base[NAJ];  // MODE 0: byte offset of (row, chunk sc); 1: byte offset of tap (0,0); 2: image index
+  unsigned a2_base[NAJ];
+  int a_iy0[NAJ], a_ix0[NAJ];
+  bool a_ok[NAJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NAJ; ++j) {
     const int64_t m = M0 + srow + PASS * j;
     a_ok[j] = m < g.M;
     a2_base[j] = 0;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
   // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform)
   auto load_tile = [&](int kt, int slot) {
     // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
-    unsigned offA[4], kw = 0;
+    unsigned offA[NAJ], kw = 0;
     bool cok = false;
     bool main_tap = true;
     const bool live = kt < g.nkt;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
         const int Wv = MODE == 2 ? g.Wup : g.Win;
         const unsigned tap_off = (unsigned)((((int64_t)ky * g.Win + kx) * g.Cin + c0) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NAJ; ++j) {
           const int vy = a_iy0[j] + ky, vx = a_ix0[j] + kx;
           const bool ok = a_ok[j] & cok & ((unsigned)vy < (unsigned)Hv) & ((unsigned)vx < (unsigned)Wv);
           unsigned off;
@@ -180,19 +182,19 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
         const int c0 = (kt - ntap_tiles) * BK;
         cok = live & (c0 + sc * 8 < g.Cin2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a2_base[j] + (unsigned)(c0 * 2) : OOB;
+        for (int j = 0; j < NAJ; ++j) offA[j] = (a_ok[j] & cok) ? a2_base[j] + (unsigned)(c0 * 2) : OOB;
         kw = (unsigned)(((int64_t)g.ks * g.ks * g.Cin + c0) * 2);
       }
     } else {
       cok = live & (kt * BK + sc * 8 < g.K);
       kw = (unsigned)(kt * BK * 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
+      for (int j = 0; j < NAJ; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
     const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
     const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma(rsel, offA[j], slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
+    for (int j = 0; j < NAJ; ++j) dma(rsel, offA[j], slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int S = decltype(slot_c)::value;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
     __syncthreads();
-    load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
-    compute(slot_c);
+    if (!(g.flags & 0x10000u)) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);  // (ablation: no DMA)
+    if (!(g.flags & 0x20000u)) compute(slot_c);                                        // (ablation: no MFMA)
   };
 
   const int nkt = g.nkt;
@@ -315,24 +317,38 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_kernel(const GemmArgs g) {
 
 template <int DT, int MODE, int NR>
 int launch_nr(GemmArgs& g, hipStream_t st) {
-  constexpr int BN = 32 * NR;
-  g.tiles_n = (g.N + BN - 1) / BN;
-  // 256-row tiles + 3-deep ring once the grid still fills the chip at one block per CU; MIMO_GEMM_CFG=1|2 forces
-  // the small / large configuration (tuning knob for A/B runs)
+  // Tile configurations (WM x WN waves, ring depth):
+  //   S  2x2, 2 stages: 128 x 32NR tile, 2 blocks/CU          — small / skinny problems
+  //   L  4x2, 3 stages: 256 x 32NR tile, 1 block/CU
+  //   XL 4x4, 2 stages: 256 x 64NR tile (N = 320 in ONE tile), 16 waves, 1 block/CU — halves the global->LDS
+  //      bytes per MAC; the L2->LDS path (~18 TB/s measured) and not the MFMAs bounds the S tile
+  // MIMO_GEMM_CFG=1|2|3 forces S|L|XL (tuning knob for A/B runs); MIMO_GEMM_ABLATE is for timing experiments.
   static const int forced = getenv("MIMO_GEMM_CFG") ? atoi(getenv("MIMO_GEMM_CFG")) : 0;
-  const int64_t big_tiles = ((g.M + 255) / 256) * g.tiles_n;
-  // measured (tools/microbench.py): the 256-row ring wins for the wide GEGLU GEMMs (NR = 4, N >= 2560: +4..10 %)
-  // and loses up to 11 % on the NR = 5 shapes, so it is selected for NR = 4 only
-  const bool big = forced == 2 || (forced == 0 && NR == 4 && big_tiles >= 512);
-  if (big) {
-    const int64_t nwg = big_tiles;
-    if (nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 3>), dim3((unsigned)nwg), dim3(512), 0, st, g);
-  } else {
-    const int64_t nwg = ((g.M + 127) / 128) * g.tiles_n;
+  static const int ablate = getenv("MIMO_GEMM_ABLATE") ? atoi(getenv("MIMO_GEMM_ABLATE")) : 0;
+  if (ablate == 1) g.flags |= 0x10000u;
+  if (ablate == 2) g.flags |= 0x20000u;
+  const int64_t m256 = (g.M + 255) / 256;
+  const int tn_s = (g.N + 32 * NR - 1) / (32 * NR), tn_xl = (g.N + 64 * NR - 1) / (64 * NR);
+  const bool geglu = g.flags & MIMO_EPI_GEGLU;
+  int cfg = forced;
+  if (cfg == 0) cfg = (m256 * tn_xl >= 384) ? 3 : 1;
+  if (cfg == 3) {
+    g.tiles_n = tn_xl;
+    const int64_t nwg = m256 * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+  } else if (cfg == 2) {
+    g.tiles_n = tn_s;
+    const int64_t nwg = m256 * tn_s;
+    if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 2, 3>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+  } else {
+    g.tiles_n = tn_s;
+    const int64_t nwg = ((g.M + 127) / 128) * tn_s;
+    if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2>), dim3((unsigned)nwg), dim3(256), 0, st, g);
   }
+  (void)geglu;
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }
