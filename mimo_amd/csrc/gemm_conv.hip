@@ -331,7 +331,7 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   const int tn_s = (g.N + 32 * NR - 1) / (32 * NR), tn_xl = (g.N + 64 * NR - 1) / (64 * NR);
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
   int cfg = forced;
-  if (cfg == 0) cfg = (m256 * tn_xl >= 384) ? 3 : 1;
+  if (cfg == 0) cfg = (m256 * tn_xl >= 160) ? 3 : 1;  // measured crossover (tools/microbench.py)
   if (cfg == 3) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
