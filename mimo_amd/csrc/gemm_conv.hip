@@ -331,7 +331,10 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   const int tn_s = (g.N + 32 * NR - 1) / (32 * NR), tn_xl = (g.N + 64 * NR - 1) / (64 * NR);
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
   int cfg = forced;
-  if (cfg == 0) cfg = (m256 * tn_xl >= 160) ? 3 : 1;  // measured crossover (tools/microbench.py)
+  if (cfg == 0) {
+    if (g.N <= 32 * NR) cfg = (m256 * tn_s >= 160) ? 2 : 1;  // one S-width tile covers N: a 64NR-wide XL tile would idle
+    else cfg = (m256 * tn_xl >= 160) ? 3 : 1;                 // measured crossover (tools/microbench.py)
+  }
   if (cfg == 3) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;

@@ -28,11 +28,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--vae", action="store_true", help="time VAE encode/decode + pose guider on 8 frames at 512x512 instead")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda:0")
     n = 48
     print(f"# dtype={a.dtype} device={torch.cuda.get_device_name(0)}")
+    if a.vae:
+        from mimo_amd.vae import AutoencoderKL, PoseGuider
+        with torch.device(dev):
+            vae, pg = AutoencoderKL(), PoseGuider()
+        torch.nn.init.normal_(pg.conv_out.weight, std=0.02)
+        for m in (vae, pg):
+            m.to(dtype=dt)
+            m.compute_dtype = dt
+        img = torch.rand(8, 512, 512, 8, device=dev).to(dt)
+        img[..., 3:] = 0
+        z = torch.randn(8, 64, 64, 8, device=dev).to(dt)
+        z[..., 4:] = 0
+        for name, fn, fl in (("vae.encode 8x512^2", lambda: vae.encode_tokens(img), 8 * 1.1167e12),
+                             ("vae.decode 8x64^2->512^2", lambda: vae.decode_tokens(z), 8 * 2.5145e12),
+                             ("pose_guider 8x512^2", lambda: pg.run_tokens(img), 8 * 0.0147e12)):
+            t = timeit(fn, iters=3, warm=1)
+            print(f"{name}: {t*1e3:8.2f} ms  {fl/t/1e12:7.1f} TF/s (algorithmic)")
+        return
     # --- 3x3 convs (n, hw, cin, cout)
     for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
