@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   constexpr int KP = KS * 16 + 8;          // K tile pitch (halfs): odd multiple of 16 bytes
   constexpr int VP = KV_TILE + 4;          // V^T tile pitch (halfs): 8 * odd bytes
   constexpr int DC = D / 8;                // 16-byte chunks per head row
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[KV_TILE * KP];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[OT * 32 * VP];
+  constexpr int NBUF = D <= 80 ? 2 : 1;   // double-buffered K / V^T tiles where LDS and registers allow it
+  constexpr int KSZ = KV_TILE * KP, VSZ = OT * 32 * VP;
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[NBUF * KSZ];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[NBUF * VSZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, li = lane & 31;
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   const int q0 = blockIdx.x * 128 + wave * 32;
 
   // zero the LDS once: pad columns / rows are never written again
-  for (int i = tid; i < KV_TILE * KP / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
-  for (int i = tid; i < OT * 32 * VP / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+  for (int i = tid; i < NBUF * KSZ / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
+  for (int i = tid; i < NBUF * VSZ / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
 
   // Q^T fragments (B operand): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8]
   uint4 qf[KS];
@@ -107,27 +109,47 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     }
   };
 
-  issue(0);
-  for (int t = 0; t < T; ++t) {
-    __syncthreads();  // tile t-1 fully consumed (first iteration: orders the zero-fill)
-    // ---- registers -> LDS: K row-major, V transposed ----
+  // registers -> LDS buffer `buf`: K row-major, V transposed
+  auto stage = [&](int buf) {
+    uint16_t* ks = Ks + buf * KSZ;
+    uint16_t* vt = Vt + buf * VSZ;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int id = tid + 256 * it;
       if (id < KV_TILE * DC) {
         const int krow = id / DC, kcc = id - krow * DC;
-        *reinterpret_cast<uint4*>(&Ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
+        *reinterpret_cast<uint4*>(&ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
         const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
         const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          Vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
-          Vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
+          vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
+          vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
         }
       }
     }
+  };
+
+  // Pipeline (NBUF = 2): ONE barrier per KV tile.  While tile t is consumed from buffer t&1, tile t+1 (already in
+  // registers) is written to the other buffer and tile t+2's global loads are issued.
+  // (NBUF = 1: barrier, stage, barrier, prefetch, consume.)
+  issue(0);
+  __syncthreads();  // orders the zero-fill
+  if (NBUF == 2) {
+    stage(0);
+    if (T > 1) issue(1);
     __syncthreads();
-    if (t + 1 < T) issue(t + 1);  // next tile's loads fly under this tile's MFMAs / softmax
+  }
+  for (int t = 0; t < T; ++t) {
+    const int cur = NBUF == 2 ? (t & 1) : 0;
+    if (NBUF == 1) {
+      if (t > 0) __syncthreads();  // tile t-1 fully consumed
+      stage(0);
+      __syncthreads();
+      if (t + 1 < T) issue(t + 1);
+    }
+    const uint16_t* ks = Ks + cur * KSZ;
+    const uint16_t* vt = Vt + cur * VSZ;
 
     const bool s2 = t >= T0;
     const int nk = s2 ? a.Nk2 : a.Nk;
@@ -135,14 +157,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 
     // ---- S^T = K.Q^T : two 32-kv sub-tiles ----
     f32x16 st[2];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
-#pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
-        st[u] = HT<DT>::mfma32(kf, qf[s], st[u]);
+        const uint4 kf = *reinterpret_cast<const uint4*>(&ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
+        st[u] = HT<DT>::mfma32(kf, qf[s], s == 0 ? zero16 : st[u]);  // C = 0 folds into the instruction
       }
     }
     // ---- online softmax over kv for this lane's query (raw-score max; scale folded into the exp2 fma) ----
@@ -200,11 +223,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     for (int dt = 0; dt < OT; ++dt) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint16_t* vr = &Vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
+        const uint16_t* vr = &vt[(32 * dt + li) * VP + 16 * u + 4 * h2];
         const uint2 lo = *reinterpret_cast<const uint2*>(vr);
         const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
         ot[dt] = HT<DT>::mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], ot[dt]);
       }
+    }
+    if (NBUF == 2 && t + 1 < T) {
+      stage(cur ^ 1);              // last read in iteration t-1, every wave has passed that iteration's barrier
+      if (t + 2 < T) issue(t + 2);
+      __syncthreads();             // publishes tile t+1; every wave is done with buffer `cur`
     }
   }
 
