@@ -35,7 +35,7 @@ struct AttnArgs {
 };
 
 template <int DT, int D>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
   constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
   constexpr int KP = KS * 16 + 8;          // K tile pitch (halfs): odd multiple of 16 bytes
@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   // zero the LDS once: pad columns / rows are never written again
   for (int i = tid; i < NBUF * KSZ / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
   for (int i = tid; i < NBUF * VSZ / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+  // When the O^T tiles have spare rows (D not a multiple of 32) row D of V^T is set to ones: the P.V MFMAs then
+  // also produce the softmax denominator sum_kv P (in the O^T accumulator row D) — no per-element VALU adds.
+  constexpr bool ONES = OT * 32 > D;
+  if (ONES) {
+    __syncthreads();
+    for (int i = tid; i < NBUF * VP; i += 256) Vt[(i / VP) * VSZ + D * VP + (i % VP)] = HT<DT>::from_f(1.0f);
+  }
 
   // Q^T fragments (B operand): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8]
   uint4 qf[KS];
@@ -87,25 +94,49 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   constexpr int NCH = (KV_TILE * DC + 255) / 256;
   u32x4 kreg[NCH], vreg[NCH];
 
+  // Per-thread staging geometry is loop-invariant: chunk `it` of a thread is (K row krow, 16-byte chunk kcc) and
+  // (V row vrow, chunk vcc).  Only the tile's first KV row moves, and it travels in the scalar soffset.
+  int krow_[NCH], vrow_[NCH];
+  unsigned kcol_[NCH], vcol_[NCH], klds_[NCH], vlds_[NCH];
+  bool live_[NCH];
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int id = tid + 256 * it;
+    live_[it] = id < KV_TILE * DC;
+    krow_[it] = id / DC;
+    const int kcc = id - krow_[it] * DC;
+    vrow_[it] = id & (KV_TILE - 1);
+    const int vcc = id >> 6;
+    kcol_[it] = (unsigned)((head * D + kcc * 8) * 2);
+    vcol_[it] = (unsigned)((head * D + vcc * 8) * 2);
+    klds_[it] = (unsigned)(krow_[it] * KP + kcc * 8);
+    vlds_[it] = (unsigned)(vcc * 8 * VP + vrow_[it]);
+  }
+  constexpr unsigned OOBA = 0x80000000u;  // stays out of range after the (< 2 GiB) soffset is added
+
   // issue every global load of tile t (buffer loads; rows past the segment end read zeros)
   auto issue = [&](int t) {
     const bool s2 = t >= T0;
     const uint16_t* kb = s2 ? a.k2 : kb0;
     const uint16_t* vb = s2 ? a.v2 : vb0;
-    const int64_t ldk = s2 ? a.ldk2 : a.ldk, ldv = s2 ? a.ldv2 : a.ldv;
+    const unsigned ldk2b = (unsigned)((s2 ? a.ldk2 : a.ldk) * 2), ldv2b = (unsigned)((s2 ? a.ldv2 : a.ldv) * 2);
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)nk * ldk * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldv * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)nk * ldk2b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldv2b), 0x00020000);
+    const unsigned ksoff = (unsigned)kv0 * ldk2b, vsoff = (unsigned)kv0 * ldv2b;
+    const bool ragged = kv0 + KV_TILE > nk;  // wave-uniform: only the last tile of a segment pays for row checks
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-      const int id = tid + 256 * it;
-      const int krow = id / DC, kcc = id - krow * DC;
-      const bool kok = (id < KV_TILE * DC) & (kv0 + krow < nk);
-      kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rk, kok ? (unsigned)(((int64_t)(kv0 + krow) * ldk + head * D + kcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
-      const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
-      const bool vok = (id < KV_TILE * DC) & (kv0 + vrow < nk);
-      vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rv, vok ? (unsigned)(((int64_t)(kv0 + vrow) * ldv + head * D + vcc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+      unsigned ko = (unsigned)krow_[it] * ldk2b + kcol_[it];
+      unsigned vo = (unsigned)vrow_[it] * ldv2b + vcol_[it];
+      bool kok = live_[it], vok = live_[it];
+      if (ragged) {
+        kok &= kv0 + krow_[it] < nk;
+        vok &= kv0 + vrow_[it] < nk;
+      }
+      kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rk, kok ? ko : OOBA, ksoff, 0);
+      vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rv, vok ? vo : OOBA, vsoff, 0);
     }
   };
 
@@ -115,16 +146,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     uint16_t* vt = Vt + buf * VSZ;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-      const int id = tid + 256 * it;
-      if (id < KV_TILE * DC) {
-        const int krow = id / DC, kcc = id - krow * DC;
-        *reinterpret_cast<uint4*>(&ks[krow * KP + kcc * 8]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
-        const int vrow = id & (KV_TILE - 1), vcc = id >> 6;
+      if (live_[it]) {
+        *reinterpret_cast<uint4*>(&ks[klds_[it]]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
         const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          vt[(vcc * 8 + 2 * i) * VP + vrow] = (uint16_t)(w[i] & 0xffffu);
-          vt[(vcc * 8 + 2 * i + 1) * VP + vrow] = (uint16_t)(w[i] >> 16);
+          vt[vlds_[it] + (2 * i) * VP] = (uint16_t)(w[i] & 0xffffu);
+          vt[vlds_[it] + (2 * i + 1) * VP] = (uint16_t)(w[i] >> 16);
         }
       }
     }
@@ -203,10 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float pv = fast_exp2(fmaf(st[u][r], c, mc));
         st[u][r] = pv;
-        ps += pv;
+        if (!ONES) ps += pv;
       }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run += ps;
+    if (!ONES) {
+      ps += __shfl_xor(ps, 32, 64);
+      l_run += ps;
+    }
 
     // ---- P^T fragments (B operand) straight from the accumulators ----
     uint4 pf[4];
@@ -237,6 +267,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   }
 
   // ---- epilogue: lane (h2, q) holds O^T[d = 32 dt + (r&3) + 8 (r>>2) + 4 h2][q] ----
+  if (ONES) {
+    // row D = 32*(OT-1) + (D & 31) of O^T: register r with (r&3) + 8*(r>>2) + 4*h2 == D & 31, held by one h2 half
+    constexpr int RL = D & 31;
+    constexpr int LH2 = (RL >> 2) & 1, LR = (RL & 3) + 4 * (RL >> 3);
+    l_run = __shfl(ot[OT - 1][LR], li + 32 * LH2, 64);
+  }
   const int qr = q0 + li;
   if (qr < a.Nq) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;

@@ -54,9 +54,16 @@ struct HT<MIMO_BF16> {
   }
 };
 
+// two floats -> one packed 16-bit pair, round-to-nearest-even, ONE instruction on gfx950
+// (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32) instead of two converts + shift + or
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <int DT>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)HT<DT>::from_f(lo) | ((uint32_t)HT<DT>::from_f(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  if (DT == MIMO_F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <int DT>
