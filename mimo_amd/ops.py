@@ -18,10 +18,32 @@ _DT = {torch.float16: L.F16, torch.bfloat16: L.BF16}
 COUNTER = None
 
 
+# Optional per-launch HIP-event brackets of the MFMA kernels (bench.py roofline of the dominant kernel family):
+# EVENTS = [] makes gemm()/conv2d()/attention() record (family, start event, end event, flops) on the launch stream.
+EVENTS = None
+
+
 def _count(flops):
     if COUNTER is not None:
         COUNTER["flops"] += flops
         COUNTER["launches"] += 1
+
+
+class _Bracket:
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if EVENTS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            EVENTS.append((self.family, self.e0, e1, self.flops))
+        return False
 
 
 def dt_code(dtype):
@@ -77,9 +99,10 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
         ldib = img_bias.stride(0)
     _count(2 * M * N * K)
-    L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
-           out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
-           float(out_scale), flags, _stream())
+    with _Bracket("gemm_kernel", 2 * M * N * K):
+        L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
+               out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
+               float(out_scale), flags, _stream())
     return out
 
 
@@ -116,9 +139,11 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == out.shape
         flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
-    _count(2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2))
-    L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
-           ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags, _stream())
+    fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
+    _count(fl)
+    with _Bracket("gemm_kernel", fl):
+        L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
+               ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags, _stream())
     return out
 
 
@@ -184,10 +209,12 @@ def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=Non
     out = torch.empty((B, Nq, C), device=q.device, dtype=q.dtype)
     if scale is None:
         scale = d ** -0.5
-    _count(4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2))
-    L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
-           v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
-           seg2_first_batch, heads, d, float(scale), _stream())
+    fl = 4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2)
+    _count(fl)
+    with _Bracket("attn_kernel", fl):
+        L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
+               v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
+               seg2_first_batch, heads, d, float(scale), _stream())
     return out
 
 

@@ -14,8 +14,11 @@ def main():
     dtype = torch.bfloat16 if "--bf16" in sys.argv else torch.float16
     dev = torch.device("cuda:0")
     pipe = bench.build_pipeline(dev, dtype)
-    t, fl, n = bench.measure_forward(pipe, dev, dtype, 512, iters=3)
+    t, fl, n, fam = bench.measure_forward(pipe, dev, dtype, 512, iters=3)
     print(f"forward {t*1e3:.1f} ms  {fl/1e12:.2f} TFLOP  {fl/t/1e12:.1f} TF/s  {n} launches", flush=True)
+    for k, d in fam.items():
+        print(f"  {k}: {d['launches']} launches, {d['ms']:.2f} ms, {d['flops']/1e12:.2f} TFLOP, {d['flops']/d['ms']/1e9:.1f} TF/s, "
+              f"avg {d['ms']*1e3/d['launches']:.1f} us", flush=True)
     torch.cuda.synchronize()
     # under rocprofv3 the interpreter can hang after the tool has written its output: give teardown 60 s, then leave
     import threading
