@@ -55,7 +55,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
-template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE, bool IL>
+template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
   constexpr int THREADS = 64 * WM * WN;
@@ -146,9 +146,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
 
   // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform)
-  unsigned pend_off[LOADS], pend_lds[LOADS];
-  i32x4 pend_rsel = make_rsrc(g.A, g.a_bytes);
-  auto prepare_tile = [&](int kt, int slot) {
+  auto load_tile = [&](int kt, int slot) {
     // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
     unsigned offA[NAJ], kw = 0;
     bool cok = false;
@@ -193,24 +191,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
 #pragma unroll
       for (int j = 0; j < NAJ; ++j) offA[j] = (a_ok[j] & cok) ? a_base[j] + kw : OOB;
     }
-    pend_rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
+    const i32x4 rsel = make_rsrc(main_tap ? g.A : g.A2, main_tap ? g.a_bytes : g.a2_bytes);
     const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int j = 0; j < NAJ; ++j) {
-      pend_off[j] = offA[j];
-      pend_lds[j] = slot_base + 16u * ((wave_u * 8 + PASS * j) * 8);
-    }
+    for (int j = 0; j < NAJ; ++j) dma(rsel, offA[j], slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
 #pragma unroll
-    for (int j = 0; j < NBJ; ++j) {
-      pend_off[NAJ + j] = (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB;
-      pend_lds[NAJ + j] = slot_base + 16u * ((BM + b_row0[j]) * 8);
-    }
-  };
-  auto issue_one = [&](int j) { dma(j < NAJ ? pend_rsel : rW, pend_off[j], pend_lds[j]); };
-  auto load_tile = [&](int kt, int slot) {
-    prepare_tile(kt, slot);
-#pragma unroll
-    for (int j = 0; j < LOADS; ++j) issue_one(j);
+    for (int j = 0; j < NBJ; ++j)
+      dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
   };
 
   f32x4 acc[NR][4];
@@ -219,10 +206,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](auto slot_c, auto il_c) {
+  auto compute = [&](auto slot_c) {
     constexpr int S = decltype(slot_c)::value;
-    constexpr bool ISSUE = decltype(il_c)::value != 0;      // spread the next tile's DMA issues between the MFMAs
-    constexpr int GAP = (2 * NR * 4) / LOADS;               // MFMAs between two DMA issues
     const uint4* sa = &smem[S * STAGE];
     const uint4* sb = &smem[S * STAGE + BM * 8];
 #pragma unroll
@@ -236,18 +221,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < 4; ++mi)
           // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
           acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
-          if (ISSUE) {
-            const int idx = (s * NR + ni) * 4 + mi;  // compile-time after unrolling
-            if (idx % GAP == GAP - 1 && idx / GAP < LOADS) {
-              __builtin_amdgcn_sched_barrier(0);
-              issue_one(idx / GAP);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
     }
   };
 
@@ -258,15 +234,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
     constexpr int S = decltype(slot_c)::value;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
     __syncthreads();
-    if (IL) {
-      // the VMEM queue of a CU is finite: issuing all LOADS DMAs of 16 waves in one burst stalls the waves at the
-      // issue, in front of their MFMAs; spreading them between the MFMAs keeps both pipes busy
-      prepare_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
-      compute(slot_c, IC<1>{});
-    } else {
-      if (!(g.flags & 0x10000u)) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);  // (ablation: no DMA)
-      if (!(g.flags & 0x20000u)) compute(slot_c, IC<0>{});                                // (ablation: no MFMA)
-    }
+    if (!(g.flags & 0x10000u)) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);  // (ablation: no DMA)
+    if (!(g.flags & 0x20000u)) compute(slot_c);                                        // (ablation: no MFMA)
   };
 
   const int nkt = g.nkt;
@@ -356,7 +325,6 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   // MIMO_GEMM_CFG=1|2|3 forces S|L|XL (tuning knob for A/B runs); MIMO_GEMM_ABLATE is for timing experiments.
   static const int forced = getenv("MIMO_GEMM_CFG") ? atoi(getenv("MIMO_GEMM_CFG")) : 0;
   static const int ablate = getenv("MIMO_GEMM_ABLATE") ? atoi(getenv("MIMO_GEMM_ABLATE")) : 0;
-  static const int il = getenv("MIMO_GEMM_IL") ? atoi(getenv("MIMO_GEMM_IL")) : 0;
   if (ablate == 1) g.flags |= 0x10000u;
   if (ablate == 2) g.flags |= 0x20000u;
   const int64_t m256 = (g.M + 255) / 256;
@@ -371,19 +339,17 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    if (il) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, true>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, false>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
   } else if (cfg == 2) {
     g.tiles_n = tn_s;
     const int64_t nwg = m256 * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 2, 3, false>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 2, 3>), dim3((unsigned)nwg), dim3(512), 0, st, g);
   } else {
     g.tiles_n = tn_s;
     const int64_t nwg = ((g.M + 127) / 128) * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    if (il) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2, true>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2, false>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2>), dim3((unsigned)nwg), dim3(256), 0, st, g);
   }
   (void)geglu;
   MIMO_LAUNCH_CHECK();
