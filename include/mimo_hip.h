@@ -108,12 +108,14 @@ int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void*
  *   replaces InflatedGroupNorm / nn.GroupNorm (+ F.silu)  src/models/resnet.py:20-28,220-221,231,237;
  *   src/models/transformer_3d.py:124; src/models/motion_module.py:154; VAE norms.
  *   x1: [n, HW, C1], x2: [n, HW, C2] (nullable, C2 = 0); each fp32 or half16 (x_is_f32).
- *   stats: fp32 [n, groups, 2] = (mean, rstd).  apply: y = (x-mean)*rstd*gamma+beta,
+ *   stats: fp32 [n, groups, 2] = (mean, rstd).  split >= 1 pixel slices per (image, group) with
+ *   partials: caller scratch fp32 [n*groups*split, 2] (split > 1 only; reduced in fixed order).  apply: y = (x-mean)*rstd*gamma+beta,
  *   optional SiLU, stored half16 [n, HW, C1+C2].  raw_out (nullable): plain half16 cast
  *   of the concatenated input (feeds the fused 1x1 shortcut / upsample conv).
  * --------------------------------------------------------------------------------- */
 int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
-                          int n, int64_t HW, int groups, float eps, float* stats, void* stream);
+                          int n, int64_t HW, int groups, float eps, float* stats, float* partials,
+                          int split, void* stream);
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);

@@ -21,9 +21,13 @@ __device__ __forceinline__ float load_elem(const void* p, bool f32, int64_t idx)
 template <int DT, int V>  // V = elements per load (2 when channels-per-group and C1 are even, else 1)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, const void* x2, int C2,
                                                        int f32, int64_t HW, int groups, float eps,
-                                                       float* stats) {
-  const int img = blockIdx.x / groups;
-  const int grp = blockIdx.x % groups;
+                                                       float* stats, float* partials, int split) {
+  // block -> (image, group, pixel slice): `split` blocks share one (image, group) when n*groups alone cannot
+  // fill the chip (VAE: 8 images x 32 groups over 1 GB); their (S, Q) partials are reduced in fixed order by
+  // gn_finalize_kernel, so the result does not depend on scheduling
+  const int ig = blockIdx.x / split, sl = blockIdx.x - ig * split;
+  const int img = ig / groups;
+  const int grp = ig % groups;
   const int C = C1 + C2;
   const int cpg = C / groups;
   const int c0 = grp * cpg;
@@ -51,9 +55,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   float sh, sh2;
   fetch2(0, c0, sh, sh2);  // same value in every thread
   const int dp = 256 / hp, dc = 256 - dp * hp;
-  int p = threadIdx.x / hp, c2 = threadIdx.x - p * hp;
+  const int per = ((int)HW + split - 1) / split;              // pixels per slice
+  const int p_lo = sl * per, p_hi = min((int)HW, p_lo + per);
+  const int e_hi = p_hi * hp;
+  int p = p_lo + threadIdx.x / hp, c2 = threadIdx.x % hp;
   float s = 0.f, q = 0.f;
-  for (int e = threadIdx.x; e < count2; e += 256) {
+  for (int e = p_lo * hp + threadIdx.x; e < e_hi; e += 256) {
     float a, b;
     fetch2(p, c0 + V * c2, a, b);
     a -= sh; b -= sh;
@@ -72,13 +79,41 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float n = (float)count2 * (float)V;
     const float S = red[0] + red[1] + red[2] + red[3], Q = red[4] + red[5] + red[6] + red[7];
-    const float ms = S / n;
-    const float var = fmaxf(Q / n - ms * ms, 0.f);
-    stats[(int64_t)blockIdx.x * 2 + 0] = sh + ms;
-    stats[(int64_t)blockIdx.x * 2 + 1] = rsqrtf(var + eps);
+    if (split > 1) {
+      partials[(int64_t)blockIdx.x * 2 + 0] = S;  // sums of (x - sh), (x - sh)^2 over this slice; sh is slice-independent
+      partials[(int64_t)blockIdx.x * 2 + 1] = Q;
+    } else {
+      const float n = (float)count2 * (float)V;
+      const float ms = S / n;
+      const float var = fmaxf(Q / n - ms * ms, 0.f);
+      stats[(int64_t)ig * 2 + 0] = sh + ms;
+      stats[(int64_t)ig * 2 + 1] = rsqrtf(var + eps);
+    }
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const void* x1, int C1, const void* x2, int C2, int f32,
+                                                          int64_t HW, int groups, int total, float eps,
+                                                          const float* partials, int split, float* stats) {
+  const int ig = blockIdx.x * 256 + threadIdx.x;
+  if (ig >= total) return;
+  const int img = ig / groups, grp = ig % groups;
+  const int cpg = (C1 + C2) / groups, c0 = grp * cpg;
+  // the shift every slice used: the group's first element
+  const float sh = c0 < C1 ? load_elem<DT>(x1, f32, (int64_t)img * HW * C1 + c0)
+                           : load_elem<DT>(x2, f32, (int64_t)img * HW * C2 + (c0 - C1));
+  double S = 0.0, Q = 0.0;
+  for (int k = 0; k < split; ++k) {
+    S += (double)partials[((int64_t)ig * split + k) * 2];
+    Q += (double)partials[((int64_t)ig * split + k) * 2 + 1];
+  }
+  const double n = (double)HW * cpg;
+  const double ms = S / n;
+  const double var = fmax(Q / n - ms * ms, 0.0);
+  stats[(int64_t)ig * 2 + 0] = sh + (float)ms;
+  stats[(int64_t)ig * 2 + 1] = rsqrtf((float)var + eps);
 }
 
 // ---------------------------------------------------------------------------------
@@ -259,15 +294,16 @@ inline unsigned stream_grid(int64_t work_items) {
 
 extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_is_f32,
                                      int dtype, int n, int64_t HW, int groups, float eps, float* stats,
-                                     void* stream) {
+                                     float* partials, int split, void* stream) {
+  if (split < 1 || (split > 1 && !partials) || split > HW) return MIMO_EINVAL;
   if (!x1 || !stats || n <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
   if ((C1 + C2) % groups) return MIMO_EINVAL;
   if (C2 > 0 && !x2) return MIMO_EINVAL;
   if (HW * ((C1 + C2) / groups) >= 0x7fffffffLL) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)(n * groups);
+  const unsigned grid = (unsigned)(n * groups * split);
   const bool v2 = (((C1 + C2) / groups) % 2 == 0) && (C1 % 2 == 0) && (C2 % 2 == 0);
-#define GNS_LAUNCH(DT, V) hipLaunchKernelGGL((gn_stats_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats)
+#define GNS_LAUNCH(DT, V) hipLaunchKernelGGL((gn_stats_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats, partials, split)
   if (dtype == MIMO_F16) {
     if (v2) GNS_LAUNCH(MIMO_F16, 2); else GNS_LAUNCH(MIMO_F16, 1);
   } else if (dtype == MIMO_BF16) {
@@ -277,6 +313,15 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
   }
 #undef GNS_LAUNCH
   MIMO_LAUNCH_CHECK();
+  if (split > 1) {
+    const int total = n * groups;
+    const unsigned fg = (unsigned)((total + 255) / 256);
+    if (dtype == MIMO_F16)
+      hipLaunchKernelGGL(gn_finalize_kernel<MIMO_F16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
+    else
+      hipLaunchKernelGGL(gn_finalize_kernel<MIMO_BF16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
+    MIMO_LAUNCH_CHECK();
+  }
   return MIMO_OK;
 }
 

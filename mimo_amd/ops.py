@@ -167,8 +167,13 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
     out = raw = stats = None
     if want_norm:
         stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
+        # few (image, group) pairs over a lot of pixels (VAE at 512x512): slice the pixels so the grid fills the chip
+        split = 1
+        if n * groups < 1024:
+            split = max(1, min(2048 // (n * groups), HW // 1024))
+        partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
         L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
-               float(eps), stats.data_ptr(), _stream())
+               float(eps), stats.data_ptr(), _ptr(partials), split, _stream())
         out = torch.empty(shape, device=x1.device, dtype=dtype)
     if want_raw:
         raw = torch.empty(shape, device=x1.device, dtype=dtype)

@@ -169,6 +169,20 @@ def test_group_norm_concat(dev, dtype, f32in, C1, C2, eps, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_group_norm_pixel_sliced_stats(dev, dtype):
+    """Few (image, group) pairs over many pixels (VAE shapes): the statistics grid is sliced along the pixels and
+    reduced in fixed order; a large common offset checks the shifted-sum variance."""
+    from mimo_amd import ops
+    n, H, W, C = 2, 96, 80, 128
+    x = rnd((n, H, W, C), dev, torch.float32, 1) * 0.5 + 7.0
+    gamma = rnd((C,), dev, torch.float32, 3) * 0.1 + 1
+    beta = rnd((C,), dev, torch.float32, 4) * 0.1
+    out, _ = ops.group_norm(x, gamma, beta, eps=1e-6, silu=True, dtype=dtype)
+    ref = F.silu(F.group_norm(x.permute(0, 3, 1, 2), 32, gamma, beta, 1e-6).permute(0, 2, 3, 1))
+    assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [320, 640, 1280])
 def test_layer_norm_and_pe(dev, dtype, C):
     from mimo_amd import ops
