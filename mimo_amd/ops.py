@@ -238,10 +238,13 @@ def temporal_attention(q, k, v, b, F, HW, heads, *, scale=None):
     return out
 
 
-def softmax_rows(x, dtype, scale=1.0):
+def softmax_rows(x, dtype, scale=1.0, out=None):
+    """Row softmax of a (row-strided) fp32 matrix into a (row-strided) half matrix."""
     _chk(x, "x")
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
-    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    assert out.shape == x.shape and out.dtype == dtype and out.stride(1) == 1
     L.call("mimo_softmax_rows", dt_code(dtype), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
            x.shape[0], x.shape[1], float(scale), _stream())
     return out

@@ -48,16 +48,19 @@ class VaeMidBlock(HipModule):
         x = self.resnets[0].run(ctx, x)
         n, H, W, C = x.shape
         N = H * W
-        if N % 8:
-            raise NotImplementedError("VAE mid-block attention needs H*W/64 to be a multiple of 8 tokens")
+        Np = (N + 7) // 8 * 8  # key count padded to the 16-byte operand granule; padded keys get probability 0
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=False, dtype=ctx.dtype)
         qkv = ops.gemm(g.view(-1, C), p["qkv_w"], bias=p["qkv_b"]).view(n, N, 3 * C)
         o = torch.empty((n, N, C), device=x.device, dtype=ctx.dtype)
+        kp = torch.zeros((Np, C), device=x.device, dtype=ctx.dtype)
+        vt = torch.zeros((C, Np), device=x.device, dtype=ctx.dtype)
+        pr = torch.zeros((N, Np), device=x.device, dtype=ctx.dtype)
         for i in range(n):  # d = 512 single head: scores / softmax / P.V as GEMM + row-softmax + GEMM
-            q, k, v = qkv[i, :, :C], qkv[i, :, C:2 * C], qkv[i, :, 2 * C:]
-            s = ops.gemm(q, k.contiguous(), out_f32=True)
-            pr = ops.softmax_rows(s, ctx.dtype, scale=C ** -0.5)
-            ops.gemm(pr, v.t().contiguous(), out=o[i])
+            kp[:N].copy_(qkv[i, :, C:2 * C])
+            vt[:, :N].copy_(qkv[i, :, 2 * C:].t())
+            s = ops.gemm(qkv[i, :, :C], kp, out_f32=True)
+            ops.softmax_rows(s[:, :N], ctx.dtype, scale=C ** -0.5, out=pr[:, :N])
+            ops.gemm(pr, vt, out=o[i])
         y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], residual=x.view(-1, C), out_f32=True).view(n, H, W, C)
         return self.resnets[1].run(ctx, y)
 

@@ -124,17 +124,18 @@ def test_pose_guider(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_vae_encode_decode(dev, dtype):
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 80)])  # 48x80: 60 mid-block tokens, not a multiple of 8 (784^2 case)
+def test_vae_encode_decode(dev, dtype, H, W):
     ov, pv = build_pair_vae(dtype, dev)
     g = torch.Generator().manual_seed(5)
-    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    img = torch.rand(2, 3, H, W, generator=g) * 2 - 1
     ref_m = ov.encode(img).latent_dist.mean
     out_m = pv.encode(img.to(dev)).latent_dist.mean.cpu()
-    z = torch.randn(2, 4, 8, 8, generator=g)
+    z = torch.randn(2, 4, H // 8, W // 8, generator=g)
     ref_d = ov.decode(z).sample
     out_d = pv.decode(z.to(dev)).sample.cpu()
     e1, e2 = rel_l2(out_m, ref_m), rel_l2(out_d, ref_d)
-    report(f"vae {dtype}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
+    report(f"vae {dtype} {H}x{W}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
     assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
 
 
