@@ -45,6 +45,10 @@ extern "C" {
 
 int mimo_version(void);
 
+/* Re-read the MIMO_GEMM_* / MIMO_CONV_* tuning environment variables (they are otherwise read once, at the first
+ * launch).  Not a reference interface: used by tools/microbench.py for interleaved A/B timing.  Returns 0. */
+int mimo_reload_tuning(void);
+
 /* ---------------------------------------------------------------------------------
  * mimo_gemm: out[M,N] = epi( A[M,K] . W[N,K]^T )
  *   replaces every nn.Linear / 1x1 nn.Conv2d on the path:

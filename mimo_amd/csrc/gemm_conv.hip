@@ -53,13 +53,15 @@ struct IC {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
-template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE>
+template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE, int MT>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
   constexpr int THREADS = 64 * WM * WN;
-  constexpr int BM = 64 * WM;
+  constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NR * WN;
   constexpr int PASS = THREADS / 8;                   // tile rows covered by one DMA pass of the whole block
   constexpr int NAJ = BM / PASS;                      // A passes
@@ -156,8 +158,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
       const int ntap_tiles = g.ks * g.ks * g.chunks1;
       main_tap = kt < ntap_tiles;
       if (main_tap) {
-        const int tap = kt / g.chunks1;
-        const int c0 = (kt - tap * g.chunks1) * BK;
+        // K order: channel chunk outer, tap inner (flag 0x80000) -> the 9 shifted re-reads of one input chunk are
+        // consecutive K-tiles and hit in L2; or tap outer, chunk inner
+        const int ntaps = g.ks * g.ks;
+        const bool tap_inner = g.flags & 0x80000u;
+        const int tap = tap_inner ? kt % ntaps : kt / g.chunks1;
+        const int c0 = (tap_inner ? kt / ntaps : kt - tap * g.chunks1) * BK;
         const int ky = tap / g.ks, kx = tap - ky * g.ks;
         cok = c0 + sc * 8 < g.Cin;
         const int Hv = MODE == 2 ? g.Hup : g.Hin;
@@ -200,32 +206,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
       dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
   };
 
-  f32x4 acc[NR][4];
+  f32x4 acc[NR][MT];
 #pragma unroll
   for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](auto slot_c) {
+  // one k32 half (s = 0 | 1) of the K-tile in ring slot S
+  auto compute = [&](auto slot_c, int s) {
     constexpr int S = decltype(slot_c)::value;
     const uint4* sa = &smem[S * STAGE];
     const uint4* sb = &smem[S * STAGE + BM * 8];
+    const int ch = (4 * s + lg) ^ (li & 7);
+    uint4 fa[MT], fb[NR];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int ch = (4 * s + lg) ^ (li & 7);
-      uint4 fa[4], fb[NR];
+    for (int mi = 0; mi < MT; ++mi) fa[mi] = sa[(wm * 16 * MT + mi * 16 + li) * 8 + ch];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = sa[(wm * 64 + mi * 16 + li) * 8 + ch];
+    for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
+    for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
-          acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
-    }
+      for (int mi = 0; mi < MT; ++mi)
+        // swapped: D[row = n-in-tile = 4*lg + r][col = m-in-tile = li]
+        acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
   };
+  // Waves that share a SIMD (w, w+4, ...) issue their DMAs at different points of the K-tile, so that a
+  // SIMD's matrix pipe is not left idle while all of its waves sit in the (slow-to-issue) DMA instructions.
+  const bool late = (g.flags & 0x40000u) && ((wave >> 2) & 1);
 
   // One K-tile: wait until everything but the newest NSTAGE-2 tiles of THIS wave has landed, barrier (all
   // waves' parts landed AND every wave is done reading the slot about to be recycled), refill that slot with
@@ -234,8 +241,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
     constexpr int S = decltype(slot_c)::value;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
     __syncthreads();
-    if (!(g.flags & 0x10000u)) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);  // (ablation: no DMA)
-    if (!(g.flags & 0x20000u)) compute(slot_c);                                        // (ablation: no MFMA)
+    const bool dma_on = !(g.flags & 0x10000u), mfma_on = !(g.flags & 0x20000u);  // (ablation switches)
+    if (dma_on && !late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
+    if (mfma_on) compute(slot_c, 0);
+    if (dma_on && late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
+    if (mfma_on) compute(slot_c, 1);
   };
 
   const int nkt = g.nkt;
@@ -249,70 +259,125 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 
   // ---- epilogue: lane holds out[m = .. + li][n = .. + 4*lg + r], r = 0..3 ----
+  // Branch-free per element: every operand goes through a buffer descriptor clipped to THIS tile's valid rows, so
+  // ragged rows / columns are hardware range checks (loads return 0, stores are dropped) and all loads of one
+  // 16-column group are issued back to back before the math.  The variants (GEGLU | residual x per-image bias) are
+  // separate straight-line instantiations selected by uniform branches.
   const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
   const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
   const bool do_silu = g.flags & MIMO_EPI_SILU;
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int64_t m = M0 + wm * 64 + mi * 16 + li;
-    if (m >= g.M) continue;
-    const int64_t img = g.img_bias ? m / g.rows_per_img : 0;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const int n_out = geglu ? g.N / 2 : g.N;
+  const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.out + M0 * g.ldo * esz_o, 0, (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
+      g.res ? (int)(((rows_valid - 1) * g.ldr + n_out) * esz_r) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
+  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
+  const int row0 = wm * 16 * MT + li;       // tile-local row of mi = 0
+  const int col0 = wn * 16 * NR + 4 * lg;   // tile-local column of ni = 0, r = 0
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+
+  auto epilogue = [&](auto has_res_c, auto has_imgb_c, auto geglu_c) {
+    constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
+    constexpr bool HAS_IMGB = decltype(has_imgb_c)::value != 0;
+    constexpr bool GEGLU = decltype(geglu_c)::value != 0;
+    // per-column-group constants: bias (for GEGLU bv[ni + 1] is the gate bias), column offsets, validity
+    f32x4 bv[NR];
+    bool col_ok[NR];
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) {
-      if (geglu && (ni & 1)) continue;
-      const int n = N0 + wn * 16 * NR + ni * 16 + 4 * lg;
-      if (n >= g.N) continue;
-      float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-      if (g.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (g.img_bias) {
-        const float4 b = *reinterpret_cast<const float4*>(g.img_bias + img * g.ldib + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      int no = n;
-      if (geglu) {
-        // gate tile = the next 16 packed columns; identical lane mapping
-        const int ni1 = (ni + 1 < NR) ? ni + 1 : ni;
-        float gt[4] = {acc[ni1][mi][0], acc[ni1][mi][1], acc[ni1][mi][2], acc[ni1][mi][3]};
-        if (g.bias) {
-          const float4 b = *reinterpret_cast<const float4*>(g.bias + n + 16);
-          gt[0] += b.x; gt[1] += b.y; gt[2] += b.z; gt[3] += b.w;
-        }
+      const int n = N0 + col0 + ni * 16;
+      col_ok[ni] = n < g.N;
+      bv[ni] = ld4(r_bias, col_ok[ni] ? (unsigned)n * 4u : OOB);
+    }
+    // rows outer, column groups inner: consecutive stores of a lane fill one output row left to right
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(gt[r]);
-        no = (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg;
-      }
-      if (do_silu) {
+    for (int mi = 0; mi < MT; ++mi) {
+      const unsigned row = (unsigned)(row0 + mi * 16);
+      f32x4 ib[NR], rr[NR];
+      if (HAS_IMGB) {  // host guarantees M < 2^31 when a per-image bias is given
+        const unsigned img_off = ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        for (int ni = 0; ni < NR; ++ni)
+          ib[ni] = ld4(r_imgb, col_ok[ni] ? img_off + (unsigned)(N0 + col0 + ni * 16) * 4u : OOB);
       }
-      if (g.res) {
+      if (HAS_RES) {
         if (res_f32) {
-          const float4 r4 = *reinterpret_cast<const float4*>((const float*)g.res + m * g.ldr + no);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni)
+            rr[ni] = ld4(r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 4u : OOB);
         } else {
-          const uint2 r2 = *reinterpret_cast<const uint2*>((const uint16_t*)g.res + m * g.ldr + no);
-          v[0] += HT<DT>::to_f((uint16_t)(r2.x & 0xffffu));
-          v[1] += HT<DT>::to_f((uint16_t)(r2.x >> 16));
-          v[2] += HT<DT>::to_f((uint16_t)(r2.y & 0xffffu));
-          v[3] += HT<DT>::to_f((uint16_t)(r2.y >> 16));
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) {
+            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(
+                r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 2u : OOB, 0, 0);
+            rr[ni] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
+                             HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+          }
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= g.out_scale;
-      if (out_f32) {
-        *reinterpret_cast<float4*>((float*)g.out + m * g.ldo + no) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 o;
-        o.x = pack2<DT>(v[0], v[1]);
-        o.y = pack2<DT>(v[2], v[3]);
-        *reinterpret_cast<uint2*>((uint16_t*)g.out + m * g.ldo + no) = o;
+      for (int ni = 0; ni < NR; ni += (GEGLU ? 2 : 1)) {
+        if (GEGLU && ni + 1 >= NR) break;
+        f32x4 v = acc[ni][mi] + bv[ni];
+        if (HAS_IMGB) v += ib[ni];
+        if (GEGLU) {
+          // gate tile = the next 16 packed columns; identical lane mapping
+          const int ng = (ni + 1 < NR) ? ni + 1 : ni;
+          const f32x4 gt = acc[ng][mi] + bv[ng];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (g.flags & 0x100000u) ? gt[r] : gelu_erf_f(gt[r]);  // (ablation: no GELU)
+        }
+        if (do_silu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
+        if (HAS_RES) v += rr[ni];
+        v *= g.out_scale;
+        const int no = GEGLU ? (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg : N0 + col0 + ni * 16;  // output column
+        const unsigned ooff = col_ok[ni] ? (row * (unsigned)g.ldo + (unsigned)no) * esz_o : OOB;
+        if (out_f32) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+        } else {
+          u32x2 o;
+          o.x = pack2<DT>(v[0], v[1]);
+          o.y = pack2<DT>(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+        }
       }
     }
-  }
+  };
+  if (geglu) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
+  else if (g.res && g.img_bias) epilogue(IC<1>{}, IC<1>{}, IC<0>{});
+  else if (g.res) epilogue(IC<1>{}, IC<0>{}, IC<0>{});
+  else if (g.img_bias) epilogue(IC<0>{}, IC<1>{}, IC<0>{});
+  else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
+}
+
+// Tuning knobs, read from the environment once (mimo_reload_tuning() re-reads them; tools/microbench.py --ab):
+//   MIMO_GEMM_CFG=1|2|3|4   force tile configuration S|L|XL|XL8
+//   MIMO_GEMM_STAGGER=0     all waves issue their DMAs right after the barrier (default 1: staggered)
+//   MIMO_CONV_TAP_INNER=0   convolution K order tap-outer / channel-chunk-inner (default 1: tap inner)
+//   MIMO_GEMM_ABLATE=1|2|3  timing experiments: skip DMA | skip MFMA | skip GELU (results are wrong)
+struct Tuning {
+  int cfg, ablate, stagger, tap_inner;
+};
+Tuning read_tuning() {
+  auto env = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
+  return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1)};
+}
+Tuning& tuning() {
+  static Tuning t = read_tuning();
+  return t;
 }
 
 template <int DT, int MODE, int NR>
@@ -322,11 +387,12 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   //   L  4x2, 3 stages: 256 x 32NR tile, 1 block/CU
   //   XL 4x4, 2 stages: 256 x 64NR tile (N = 320 in ONE tile), 16 waves, 1 block/CU — halves the global->LDS
   //      bytes per MAC; the L2->LDS path (~18 TB/s measured) and not the MFMAs bounds the S tile
-  // MIMO_GEMM_CFG=1|2|3 forces S|L|XL (tuning knob for A/B runs); MIMO_GEMM_ABLATE is for timing experiments.
-  static const int forced = getenv("MIMO_GEMM_CFG") ? atoi(getenv("MIMO_GEMM_CFG")) : 0;
-  static const int ablate = getenv("MIMO_GEMM_ABLATE") ? atoi(getenv("MIMO_GEMM_ABLATE")) : 0;
+  //   XL8 2x4, 2 stages: the XL tile on 8 waves of 128 x 16NR (256-register budget) — every NR = 5 XL problem
+  const Tuning& tn = tuning();
+  const int forced = tn.cfg, ablate = tn.ablate;
   if (ablate == 1) g.flags |= 0x10000u;
   if (ablate == 2) g.flags |= 0x20000u;
+  if (ablate == 3) g.flags |= 0x100000u;
   const int64_t m256 = (g.M + 255) / 256;
   const int tn_s = (g.N + 32 * NR - 1) / (32 * NR), tn_xl = (g.N + 64 * NR - 1) / (64 * NR);
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
@@ -335,21 +401,30 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     if (g.N <= 32 * NR) cfg = (m256 * tn_s >= 160) ? 2 : 1;  // one S-width tile covers N: a 64NR-wide XL tile would idle
     else cfg = (m256 * tn_xl >= 160) ? 3 : 1;                 // measured crossover (tools/microbench.py)
   }
-  if (cfg == 3) {
+  if (tn.stagger) g.flags |= 0x40000u;
+  if (tn.tap_inner && MODE != 0) g.flags |= 0x80000u;
+  if (cfg == 3 && NR == 5) cfg = 4;  // 16 waves x 128 registers cannot hold a 64 x 80 accumulator tile plus the epilogue
+  if (cfg == 4) {  // XL8: the XL tile on 8 waves (2 x 4), each wave 128 x 16NR with a 256-register budget
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+  } else if (cfg == 3) {
+    g.tiles_n = tn_xl;
+    const int64_t nwg = m256 * tn_xl;
+    if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    if constexpr (NR == 4)
+      hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, 4>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
   } else if (cfg == 2) {
     g.tiles_n = tn_s;
     const int64_t nwg = m256 * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 2, 3>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 2, 3, 4>), dim3((unsigned)nwg), dim3(512), 0, st, g);
   } else {
     g.tiles_n = tn_s;
     const int64_t nwg = ((g.M + 127) / 128) * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2, 4>), dim3((unsigned)nwg), dim3(256), 0, st, g);
   }
   (void)geglu;
   MIMO_LAUNCH_CHECK();
@@ -435,4 +510,9 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   return MIMO_EDTYPE;
 }
 
-extern "C" int mimo_version(void) { return 2; }
+extern "C" int mimo_version(void) { return 3; }
+
+extern "C" int mimo_reload_tuning(void) {
+  tuning() = read_tuning();
+  return MIMO_OK;
+}

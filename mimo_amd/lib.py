@@ -25,6 +25,7 @@ class ConvParams(ctypes.Structure):
 # name -> argtypes, mirrors include/mimo_hip.h one to one
 SIGNATURES = {
     "mimo_version": [],
+    "mimo_reload_tuning": [],
     "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp],
     "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],

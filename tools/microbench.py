@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mimo_amd import ops  # noqa: E402
+from mimo_amd import lib as L, ops  # noqa: E402
 from mimo_amd.packing import pack_conv, pack_geglu  # noqa: E402
 
 
@@ -24,16 +24,62 @@ def timeit(fn, iters=10, warm=3):
     return st.elapsed_time(en) / iters * 1e-3
 
 
+def ab_table(settings, dt, dev, n):
+    """Interleaved A/B: every shape is timed under every knob setting in turn, 3 rounds, best median kept."""
+    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_PERSIST", "MIMO_GEMM_ABLATE")
+    cases = []
+    for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
+        x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
+        w = pack_conv(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, dt)
+        b = torch.zeros(cout, device=dev)
+        cases.append((f"conv3x3 {hw}x{hw} {cin}->{cout}", (lambda x=x, w=w, b=b, cout=cout: ops.conv2d(x, w, cout, bias=b, out_f32=True)),
+                      2 * n * hw * hw * cout * 9 * cin))
+    for (M, N, K) in [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (49152, 640, 2560),
+                      (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
+        A = torch.randn(M, K, device=dev).to(dt)
+        W = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+        R = torch.randn(M, N, device=dev)
+        cases.append((f"gemm M{M} N{N} K{K}", (lambda A=A, W=W: ops.gemm(A, W)), 2 * M * N * K))
+        if N == 320 or K == 2560:
+            cases.append((f"gemm+res32 M{M} N{N} K{K}", (lambda A=A, W=W, R=R: ops.gemm(A, W, residual=R, out_f32=True)), 2 * M * N * K))
+    for (M, dim) in [(196608, 320), (49152, 640), (12288, 1280)]:
+        A = torch.randn(M, dim, device=dev).to(dt)
+        wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
+        cases.append((f"geglu-ff1 M{M} dim{dim}", (lambda A=A, wp=wp, bp=bp: ops.gemm(A, wp, bias=bp, geglu=True)), 2 * M * 8 * dim * dim))
+    print("setting index: " + "  ".join(f"[{i}] {s or 'default'}" for i, s in enumerate(settings)))
+    print(f"{'case':36s} " + " ".join(f"{'['+str(i)+'] ms':>9s} {'TF/s':>7s}" for i in range(len(settings))))
+    for name, fn, fl in cases:
+        best = [float("inf")] * len(settings)
+        for _ in range(3):
+            for i, sset in enumerate(settings):
+                for k in knobs:
+                    os.environ.pop(k, None)
+                for kv in filter(None, sset.split(",")):
+                    k, v = kv.split("=")
+                    os.environ[k] = v
+                L.call("mimo_reload_tuning")
+                best[i] = min(best[i], timeit(fn, iters=20, warm=2))
+        print(f"{name:36s} " + " ".join(f"{t*1e3:9.3f} {fl/t/1e12:7.1f}" for t in best), flush=True)
+    for k in knobs:
+        os.environ.pop(k, None)
+    L.call("mimo_reload_tuning")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--mm", action="store_true", help="only the gemm_kernel family (convs, linears, GEGLU)")
+    ap.add_argument("--ab", default="", help="A/B table of the gemm_kernel family over tuning-knob settings, e.g. "
+                    "'MIMO_GEMM_CFG=3;MIMO_GEMM_CFG=4,MIMO_GEMM_STAGGER=1' (settings separated by ';')")
     ap.add_argument("--vae", action="store_true", help="time VAE encode/decode + pose guider on 8 frames at 512x512 instead")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda:0")
     n = 48
     print(f"# dtype={a.dtype} device={torch.cuda.get_device_name(0)}")
+    if a.ab:
+        return ab_table(a.ab.split(";"), dt, dev, n)
     if a.vae:
         from mimo_amd.vae import AutoencoderKL, PoseGuider
         with torch.device(dev):
@@ -71,6 +117,8 @@ def main():
         wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
         t = timeit(lambda: ops.gemm(A, wp, bias=bp, geglu=True))
         print(f"geglu-ff1 M{M} dim{dim}: {t*1e3:8.3f} ms  {2*M*8*dim*dim/t/1e12:7.1f} TF/s")
+    if a.mm:
+        return
     # --- spatial attention, 24 uncond + 24 cond (bank)
     for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
         qkv = torch.randn(n, N, 3 * C, device=dev).to(dt)
