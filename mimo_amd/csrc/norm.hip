@@ -93,6 +93,85 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x1, int C1, c
   }
 }
 
+// GroupNorm statistics, row-streaming form: one block per (image, pixel slice) covers ALL groups.  A thread owns
+// 4 consecutive channels and walks the slice's pixels, so every wave instruction reads whole contiguous pixel rows
+// (the per-(image, group) form above touches 4*cpg bytes out of every C*4-byte row and makes each XCD's L2 fetch
+// every line).  Same shifted sums (shift = the group's first element of the image), reduced per group in a fixed
+// order and written as (S, Q) partials for gn_finalize_kernel.
+template <int DT>
+__global__ __launch_bounds__(1024) void gn_stats_rows_kernel(const void* x1, int C1, const void* x2, int C2, int f32,
+                                                             int64_t HW, int groups, float* partials, int split) {
+  const int C = C1 + C2, cpg = C / groups, c4 = C >> 2;
+  const int R = blockDim.x / c4;  // pixels per block pass
+  const int img = blockIdx.x / split, sl = blockIdx.x - img * split;
+  const int per = ((int)HW + split - 1) / split;
+  const int p_lo = sl * per, p_hi = min((int)HW, p_lo + per);
+  const int tid = threadIdx.x;
+  const int r = tid / c4, ch = (tid - r * c4) * 4;
+  const bool first = ch < C1;
+  const int Cx = first ? C1 : C2, cx = first ? ch : ch - C1;
+  const void* src = first ? x1 : x2;
+  const int64_t img_base = (int64_t)img * HW * Cx + cx;
+  float sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g0 = ((ch + j) / cpg) * cpg;  // first channel of this channel's group
+    sh[j] = g0 < C1 ? load_elem<DT>(x1, f32, (int64_t)img * HW * C1 + g0)
+                    : load_elem<DT>(x2, f32, (int64_t)img * HW * C2 + (g0 - C1));
+  }
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int p, float (&v)[4]) {
+    const int64_t idx = img_base + (int64_t)p * Cx;
+    if (f32) {
+      const float4 t = *reinterpret_cast<const float4*>((const float*)src + idx);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      const uint2 t = *reinterpret_cast<const uint2*>((const uint16_t*)src + idx);
+      v[0] = HT<DT>::to_f((uint16_t)(t.x & 0xffffu)); v[1] = HT<DT>::to_f((uint16_t)(t.x >> 16));
+      v[2] = HT<DT>::to_f((uint16_t)(t.y & 0xffffu)); v[3] = HT<DT>::to_f((uint16_t)(t.y >> 16));
+    }
+  };
+  auto accum = [&](const float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = v[j] - sh[j];
+      s[j] += a;
+      q[j] = fmaf(a, a, q[j]);
+    }
+  };
+  int p = p_lo + r;
+  for (; p + 3 * R < p_hi; p += 4 * R) {  // four rows in flight per thread
+    float v0[4], v1[4], v2[4], v3[4];
+    fetch(p, v0); fetch(p + R, v1); fetch(p + 2 * R, v2); fetch(p + 3 * R, v3);
+    accum(v0); accum(v1); accum(v2); accum(v3);
+  }
+  for (; p < p_hi; p += R) {
+    float v0[4];
+    fetch(p, v0);
+    accum(v0);
+  }
+  // per-group reduction in a fixed order: channel-major, then pixel-row r
+  extern __shared__ float red_rows[];  // [blockDim.x][8]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red_rows[tid * 8 + j] = s[j];
+    red_rows[tid * 8 + 4 + j] = q[j];
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float S = 0.f, Q = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+      for (int rr = 0; rr < R; ++rr) {
+        const int t = rr * c4 + (c >> 2);
+        S += red_rows[t * 8 + (c & 3)];
+        Q += red_rows[t * 8 + 4 + (c & 3)];
+      }
+    const int64_t o = (((int64_t)img * groups + tid) * split + sl) * 2;
+    partials[o] = S;
+    partials[o + 1] = Q;
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const void* x1, int C1, const void* x2, int C2, int f32,
                                                           int64_t HW, int groups, int total, float eps,
@@ -301,6 +380,31 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
   if (C2 > 0 && !x2) return MIMO_EINVAL;
   if (HW * ((C1 + C2) / groups) >= 0x7fffffffLL) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // row-streaming form: whenever the caller provides the partials buffer and the channel layout allows it
+  const int C = C1 + C2;
+  const bool rows_form = partials && !(C1 & 3) && !(C2 & 3) && (C >> 2) <= 1024 && groups <= (C >> 2) && split >= 1;
+  if (rows_form) {
+    if (dtype != MIMO_F16 && dtype != MIMO_BF16) return MIMO_EDTYPE;
+    const int c4 = C >> 2;
+    int R = 512 / c4;
+    if (R < 1) R = 1;
+    const unsigned threads = (unsigned)(c4 * R);
+    const unsigned rgrid = (unsigned)(n * split);
+    const size_t lds = (size_t)threads * 8 * sizeof(float);
+    if (dtype == MIMO_F16)
+      hipLaunchKernelGGL(gn_stats_rows_kernel<MIMO_F16>, dim3(rgrid), dim3(threads), lds, st, x1, C1, x2, C2, x_is_f32, HW, groups, partials, split);
+    else
+      hipLaunchKernelGGL(gn_stats_rows_kernel<MIMO_BF16>, dim3(rgrid), dim3(threads), lds, st, x1, C1, x2, C2, x_is_f32, HW, groups, partials, split);
+    MIMO_LAUNCH_CHECK();
+    const int total = n * groups;
+    const unsigned fg = (unsigned)((total + 255) / 256);
+    if (dtype == MIMO_F16)
+      hipLaunchKernelGGL(gn_finalize_kernel<MIMO_F16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
+    else
+      hipLaunchKernelGGL(gn_finalize_kernel<MIMO_BF16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
+    MIMO_LAUNCH_CHECK();
+    return MIMO_OK;
+  }
   const unsigned grid = (unsigned)(n * groups * split);
   const bool v2 = (((C1 + C2) / groups) % 2 == 0) && (C1 % 2 == 0) && (C2 % 2 == 0);
 #define GNS_LAUNCH(DT, V) hipLaunchKernelGGL((gn_stats_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, eps, stats, partials, split)

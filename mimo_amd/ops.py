@@ -167,11 +167,18 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
     out = raw = stats = None
     if want_norm:
         stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
-        # few (image, group) pairs over a lot of pixels (VAE at 512x512): slice the pixels so the grid fills the chip
-        split = 1
-        if n * groups < 1024:
-            split = max(1, min(2048 // (n * groups), HW // 1024))
-        partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
+        C = C1 + C2
+        if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
+            # row-streaming statistics: one block per (image, pixel slice) reads whole pixel rows; the slices'
+            # (S, Q) partials are reduced in fixed order (deterministic)
+            split = max(1, min(-(-2048 // n), HW // 16))
+            partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32)
+        else:
+            # one block per (image, group); few pairs over a lot of pixels: slice the pixels to fill the chip
+            split = 1
+            if n * groups < 1024:
+                split = max(1, min(2048 // (n * groups), HW // 1024))
+            partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
         L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
                float(eps), stats.data_ptr(), _ptr(partials), split, _stream())
         out = torch.empty(shape, device=x1.device, dtype=dtype)

@@ -69,6 +69,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--norms", action="store_true", help="only the norm kernels")
     ap.add_argument("--mm", action="store_true", help="only the gemm_kernel family (convs, linears, GEGLU)")
     ap.add_argument("--ab", default="", help="A/B table of the gemm_kernel family over tuning-knob settings, e.g. "
                     "'MIMO_GEMM_CFG=3;MIMO_GEMM_CFG=4,MIMO_GEMM_STAGGER=1' (settings separated by ';')")
@@ -99,7 +100,7 @@ def main():
             print(f"{name}: {t*1e3:8.2f} ms  {fl/t/1e12:7.1f} TF/s (algorithmic)")
         return
     # --- 3x3 convs (n, hw, cin, cout)
-    for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
+    for (hw, cin, cout) in [] if a.norms else [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
         w = pack_conv(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, dt)
         b = torch.zeros(cout, device=dev)
@@ -107,12 +108,12 @@ def main():
         fl = 2 * n * hw * hw * cout * 9 * cin
         print(f"conv3x3 n{n} {hw}x{hw} {cin}->{cout}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
     # --- GEMMs (M, N, K)
-    for (M, N, K) in [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
+    for (M, N, K) in [] if a.norms else [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) * 0.02).to(dt)
         t = timeit(lambda: ops.gemm(A, W))
         print(f"gemm M{M} N{N} K{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s")
-    for (M, dim) in [(196608, 320), (49152, 640), (12288, 1280)]:
+    for (M, dim) in [] if a.norms else [(196608, 320), (49152, 640), (12288, 1280)]:
         A = torch.randn(M, dim, device=dev).to(dt)
         wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
         t = timeit(lambda: ops.gemm(A, wp, bias=bp, geglu=True))
@@ -120,7 +121,7 @@ def main():
     if a.mm:
         return
     # --- spatial attention, 24 uncond + 24 cond (bank)
-    for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
+    for (N, C) in [] if a.norms else [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
         qkv = torch.randn(n, N, 3 * C, device=dev).to(dt)
         bank = torch.randn(N, 2 * C, device=dev).to(dt)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
@@ -140,6 +141,11 @@ def main():
         b = torch.zeros(C, device=dev)
         t = timeit(lambda: ops.group_norm(x, g, b, silu=True, dtype=dt))
         print(f"groupnorm+silu n{n} {hw}x{hw} C{C}: {t*1e3:8.3f} ms  {x.numel()*(4+4+2)/t/1e9:7.1f} GB/s(2R+1W)")
+        st = torch.empty(n, 32, 2, device=dev)
+        o = torch.empty(x.shape, device=dev, dtype=dt)
+        t = timeit(lambda: L.call("mimo_group_norm_apply", x.data_ptr(), C, None, 0, 1, ops.dt_code(dt), n, hw * hw, 32,
+                                  st.data_ptr(), g.data_ptr(), b.data_ptr(), 1, o.data_ptr(), None, None))
+        print(f"  gn apply only: {t*1e3:8.3f} ms  {x.numel()*6/t/1e9:7.1f} GB/s(1R+1W)")
         t = timeit(lambda: ops.layer_norm(x.view(-1, C), g, b, dtype=dt))
         print(f"layernorm rows{n*hw*hw} C{C}: {t*1e3:8.3f} ms  {x.numel()*6/t/1e9:7.1f} GB/s")
 
