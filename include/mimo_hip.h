@@ -143,6 +143,9 @@ int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C,
  *   rows attend self) and in write mode / plain self-attention (:137-147).
  *   q,k,v: half16 token-major [B, Nq|Nk, ld*] with head h at columns [h*d, (h+1)*d);
  *   k2,v2: half16 [Nk2, ld*2] (nullable).  out: half16 [B, Nq, ldo].  d % 8 == 0, d <= 160.
+ *   scale > 0: softmax(scale * q.k^T).  scale <= 0: q is ALREADY multiplied by scale * log2(e) (the
+ *   caller folded it into W_q); for d = 40 this selects the kernel variant whose softmax has no
+ *   per-score multiply/subtract (the running max rides in a spare MFMA k-slot).
  * --------------------------------------------------------------------------------- */
 int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                    int64_t ldv, const void* k2, int64_t ldk2, const void* v2, int64_t ldv2, void* out,

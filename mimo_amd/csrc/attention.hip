@@ -32,9 +32,10 @@ struct AttnArgs {
   int64_t ldq, ldk, ldv, ldk2, ldv2, ldo;
   int B, Nq, Nk, Nk2, seg2_first_batch, heads;
   float scale_log2;
+  int prescaled;  // Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
 };
 
-template <int DT, int D>
+template <int DT, int D, bool FAST>
 __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
   constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
@@ -57,10 +58,16 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
   // When the O^T tiles have spare rows (D not a multiple of 32) row D of V^T is set to ones: the P.V MFMAs then
   // also produce the softmax denominator sum_kv P (in the O^T accumulator row D) — no per-element VALU adds.
   constexpr bool ONES = OT * 32 > D;
-  if (ONES) {
-    __syncthreads();
+  // Spare K column D (when D is not a multiple of 16) is set to ones as well: with Q^T row D = -m the QK^T MFMAs
+  // deliver S - m directly and the softmax needs no per-score subtract (fast path below).
+  constexpr bool BIASCOL = KS * 16 > D;
+  constexpr bool fast = FAST;
+  static_assert(!FAST || BIASCOL, "the fast softmax path needs a spare K column");
+  if (ONES || BIASCOL) __syncthreads();
+  if (ONES)
     for (int i = tid; i < NBUF * VP; i += 256) Vt[(i / VP) * VSZ + D * VP + (i % VP)] = HT<DT>::from_f(1.0f);
-  }
+  if (BIASCOL && fast)
+    for (int i = tid; i < NBUF * KV_TILE; i += 256) Ks[(i / KV_TILE) * KSZ + (i % KV_TILE) * KP + D] = HT<DT>::from_f(1.0f);
 
   // Q^T fragments (B operand): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8]
   uint4 qf[KS];
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // running max in RAW score units (the scale is folded into the exp2 fma)
+  float mq = 0.f;                         // fast path: integer reference max currently folded into Q^T row D
   const float c = a.scale_log2;
 
   // flattened KV-tile list: the self segment, then (cond rows only) the bank segment
@@ -212,6 +220,49 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[u][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    if (fast) {
+      // st already is (score in log2 units) - mq, mq = this query's INTEGER reference max carried in Q^T row D
+      // (exact in half precision and in the MFMA accumulate).  Any reference within THR of the true running max
+      // is exact softmax arithmetic (p <= 2^THR, sums in fp32), so it only moves when a tile overshoots it.
+      constexpr float THR = 6.f;
+      const bool need = (t == 0) | (mt > THR);
+      if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+        float dlt = need ? ceilf(mt) : 0.f;
+        dlt = fminf(fmaxf(dlt, -2000.f - mq), 2000.f - mq);  // keeps |mq| an exactly representable integer
+        if (t != 0) {
+          const float alpha = fast_exp2(-dlt);
+#pragma unroll
+          for (int dt = 0; dt < OT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+          if (!ONES) l_run *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[u][r] -= dlt;
+        mq += dlt;
+        if (h2 == (D & 15) / 8) {  // the lane half whose fragment holds Q^T row D
+          constexpr int E = D & 7;
+          uint32_t* w = &qf[KS - 1].x + E / 2;
+          const uint32_t hb = HT<DT>::from_f(-mq);
+          *w = (E & 1) ? ((*w & 0x0000ffffu) | (hb << 16)) : ((*w & 0xffff0000u) | hb);
+        }
+      }
+      float ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(st[u][r]);
+          st[u][r] = pv;
+          if (!ONES) ps += pv;
+        }
+      if (!ONES) {
+        ps += __shfl_xor(ps, 32, 64);
+        l_run += ps;
+      }
+    } else {
     const float m_new = fmaxf(m_run, mt);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {  // some lane's max moved: rescale (rare after a few tiles)
@@ -236,6 +287,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
     if (!ONES) {
       ps += __shfl_xor(ps, 32, 64);
       l_run += ps;
+    }
     }
 
     // ---- P^T fragments (B operand) straight from the accumulators ----
@@ -451,13 +503,19 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
   a.out = (uint16_t*)out;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldk2 = ldk2; a.ldv2 = ldv2; a.ldo = ldo;
   a.B = B; a.Nq = Nq; a.Nk = Nk; a.Nk2 = Nk2; a.seg2_first_batch = seg2_first_batch; a.heads = heads;
-  a.scale_log2 = scale * LOG2E;
+  a.scale_log2 = scale > 0.f ? scale * LOG2E : 1.0f;
+  a.prescaled = scale > 0.f ? 0 : 1;  // scale <= 0: Q is pre-multiplied by softmax_scale * log2(e)
   const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
-#define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD>), grid, dim3(256), 0, st, a)
+#define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD, false>), grid, dim3(256), 0, st, a)
+#define ATTN_LAUNCH40(DT)                                                                          \
+  do {                                                                                             \
+    if (a.prescaled) hipLaunchKernelGGL((attn_kernel<DT, 40, true>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((attn_kernel<DT, 40, false>), grid, dim3(256), 0, st, a);              \
+  } while (0)
   if (dtype == MIMO_F16) {
     switch (d) {
-      case 40: ATTN_LAUNCH(MIMO_F16, 40); break;
+      case 40: ATTN_LAUNCH40(MIMO_F16); break;
       case 64: ATTN_LAUNCH(MIMO_F16, 64); break;
       case 80: ATTN_LAUNCH(MIMO_F16, 80); break;
       case 160: ATTN_LAUNCH(MIMO_F16, 160); break;
@@ -465,7 +523,7 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
     }
   } else if (dtype == MIMO_BF16) {
     switch (d) {
-      case 40: ATTN_LAUNCH(MIMO_BF16, 40); break;
+      case 40: ATTN_LAUNCH40(MIMO_BF16); break;
       case 64: ATTN_LAUNCH(MIMO_BF16, 64); break;
       case 80: ATTN_LAUNCH(MIMO_BF16, 80); break;
       case 160: ATTN_LAUNCH(MIMO_BF16, 160); break;
@@ -475,6 +533,7 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
     return MIMO_EDTYPE;
   }
 #undef ATTN_LAUNCH
+#undef ATTN_LAUNCH40
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }

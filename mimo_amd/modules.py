@@ -27,6 +27,9 @@ from . import ops
 from .packing import pack_conv, pack_geglu
 
 
+LOG2E = 1.4426950408889634
+
+
 class Ctx:
     """Per-forward execution context."""
 
@@ -209,7 +212,9 @@ class SpatialTransformerBlock(HipModule):
         a1 = self.attn1
         ff1_w, ff1_b = pack_geglu(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, dt)
         return dict(
-            qkv=torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
+            # W_q carries softmax_scale * log2(e): the attention kernel then exponentiates the MFMA result as is
+            qkv=torch.cat([a1.to_q.weight.detach().float() * ((self.dim // self.heads) ** -0.5 * LOG2E),
+                           a1.to_k.weight.detach().float(), a1.to_v.weight.detach().float()], 0).to(dt).contiguous(),
             kv=torch.cat([a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
             o_w=a1.to_out[0].weight.detach().to(dt).contiguous(), o_b=_f32(a1.to_out[0].bias),
             ff1_w=ff1_w, ff1_b=ff1_b, ff2_w=self.ff.net[2].weight.detach().to(dt).contiguous(),
@@ -239,9 +244,9 @@ class SpatialTransformerBlock(HipModule):
             # rows [0, F) of a CFG batch are unconditional: self-attention only (mutual_self_attention.py:179-197)
             first = ctx.F if ctx.b == 2 else 0
             o = ops.attention(q, k, v, self.heads, k2=self.bank_kv[:, :C], v2=self.bank_kv[:, C:],
-                              seg2_first_batch=first)
+                              seg2_first_batch=first, q_prescaled=True)
         else:
-            o = ops.attention(q, k, v, self.heads)
+            o = ops.attention(q, k, v, self.heads, q_prescaled=True)
         s, e = self.attn2_slice
         y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
                      rows_per_img=ctx.F * N, residual=t, out_f32=True)

@@ -203,7 +203,7 @@ def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=
     return out
 
 
-def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=None):
+def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=None, q_prescaled=False):
     """Multi-head attention.  q: [B, Nq, C] view, k/v: [B, Nk, C] views (last stride 1, batch stride =
     N * row stride); optional shared second segment k2/v2: [Nk2, C] views for batches >= seg2_first_batch."""
     _chk(q, "q")
@@ -219,7 +219,9 @@ def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=Non
         assert k2.stride(1) == 1 and v2.stride(1) == 1
         ldk2, ldv2 = k2.stride(0), v2.stride(0)
     out = torch.empty((B, Nq, C), device=q.device, dtype=q.dtype)
-    if scale is None:
+    if q_prescaled:
+        scale = 0.0  # C-ABI convention: scale <= 0 <=> q already carries softmax_scale * log2(e)
+    elif scale is None:
         scale = d ** -0.5
     fl = 4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2)
     _count(fl)

@@ -247,6 +247,38 @@ def test_attention_forced_rescale(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,N,Nb,spike", [(40, 256, 256, False), (40, 130, 70, False), (40, 192, 0, True), (40, 200, 64, True),
+                                          (80, 100, 100, False), (160, 64, 0, True)])
+def test_attention_prescaled_q(dev, dtype, d, N, Nb, spike):
+    """q already carries softmax_scale * log2(e) (folded into W_q): C-ABI scale <= 0.  d = 40 runs the variant that
+    keeps an integer reference max in a spare MFMA k-slot; the spike forces that reference to move in a late tile,
+    and a strongly negative first tile exercises the downward move."""
+    from mimo_amd import ops
+    heads, B = 4, 4
+    C = heads * d
+    g = 1.4426950408889634 * d ** -0.5
+    qkv = rnd((B, N, 3 * C), dev, dtype, 11)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    if spike:
+        k[1, N - 20] = (q[1, 7].float() * 4).to(dtype)   # late huge score for query 7 of batch 1
+        k[0, :64] = (-q[0, 5].float() * 2).to(dtype)     # whole first tile strongly negative for query 5 of batch 0
+    qs = (q.float() * g).to(dtype)                        # what the GEMM with the folded W_q would have produced
+    q_eff = qs.float() / g                                # the reference sees exactly the rounded operand
+    kw = {}
+    if Nb:
+        bank = rnd((Nb, 2 * C), dev, dtype, 12)
+        kw = dict(k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=2)
+        ref_u = sdpa_ref(q_eff[:2], k[:2], v[:2], heads)
+        kc = torch.cat([k[2:], kw["k2"][None].expand(2, -1, -1)], dim=1)
+        vc = torch.cat([v[2:], kw["v2"][None].expand(2, -1, -1)], dim=1)
+        ref = torch.cat([ref_u, sdpa_ref(q_eff[2:], kc, vc, heads)], dim=0)
+    else:
+        ref = sdpa_ref(q_eff, k, v, heads)
+    out = ops.attention(qs, k, v, heads, q_prescaled=True, **kw)
+    assert rel_l2(out.float(), ref) < 2.5 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("d,Fr,HW", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 5), (160, 3, 7)])
 def test_temporal_attention(dev, dtype, d, Fr, HW):
     from mimo_amd import ops

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--norms", action="store_true", help="only the norm kernels")
+    ap.add_argument("--attn", action="store_true", help="only the spatial attention kernel")
     ap.add_argument("--mm", action="store_true", help="only the gemm_kernel family (convs, linears, GEGLU)")
     ap.add_argument("--ab", default="", help="A/B table of the gemm_kernel family over tuning-knob settings, e.g. "
                     "'MIMO_GEMM_CFG=3;MIMO_GEMM_CFG=4,MIMO_GEMM_STAGGER=1' (settings separated by ';')")
@@ -100,7 +101,7 @@ def main():
             print(f"{name}: {t*1e3:8.2f} ms  {fl/t/1e12:7.1f} TF/s (algorithmic)")
         return
     # --- 3x3 convs (n, hw, cin, cout)
-    for (hw, cin, cout) in [] if a.norms else [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
+    for (hw, cin, cout) in [] if (a.norms or a.attn) else [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
         w = pack_conv(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, dt)
         b = torch.zeros(cout, device=dev)
@@ -108,12 +109,12 @@ def main():
         fl = 2 * n * hw * hw * cout * 9 * cin
         print(f"conv3x3 n{n} {hw}x{hw} {cin}->{cout}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
     # --- GEMMs (M, N, K)
-    for (M, N, K) in [] if a.norms else [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
+    for (M, N, K) in [] if (a.norms or a.attn) else [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280)]:
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) * 0.02).to(dt)
         t = timeit(lambda: ops.gemm(A, W))
         print(f"gemm M{M} N{N} K{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s")
-    for (M, dim) in [] if a.norms else [(196608, 320), (49152, 640), (12288, 1280)]:
+    for (M, dim) in [] if (a.norms or a.attn) else [(196608, 320), (49152, 640), (12288, 1280)]:
         A = torch.randn(M, dim, device=dev).to(dt)
         wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
         t = timeit(lambda: ops.gemm(A, wp, bias=bp, geglu=True))
@@ -128,6 +129,10 @@ def main():
         t = timeit(lambda: ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=24))
         fl = 4 * N * C * (24 * N + 24 * 2 * N)
         print(f"attn N{N} C{C} d{C//8}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
+        t = timeit(lambda: ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=24, q_prescaled=True))
+        print(f"attn N{N} C{C} d{C//8} (q prescaled): {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
+    if a.attn:
+        return
     # --- temporal attention
     for (HW, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
         qkv = torch.randn(2 * 24 * HW, 3 * C, device=dev).to(dt)
