@@ -45,6 +45,13 @@ extern "C" {
 
 int mimo_version(void);
 
+/* Workspace convention (mimo_gemm / mimo_conv2d): the caller MAY pass a 16-byte-aligned device scratch buffer.  It is
+ * only used to split a long K reduction over several workgroups when the output has too few tiles to fill the chip
+ * (fp32 partial tiles, reduced in a fixed order by a second launch on the same stream); with workspace == NULL or
+ * workspace_bytes too small the call runs unsplit.  mimo_workspace_bytes() is sufficient for every call with
+ * M * N <= 2^22 output elements (the SD1.5 8x8 level at 48 images); the library never allocates device memory. */
+size_t mimo_workspace_bytes(void);
+
 /* Re-read the MIMO_GEMM_* / MIMO_CONV_* tuning environment variables (they are otherwise read once, at the first
  * launch).  Not a reference interface: used by tools/microbench.py for interleaved A/B timing.  Returns 0. */
 int mimo_reload_tuning(void);
@@ -69,7 +76,7 @@ int mimo_reload_tuning(void);
 int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
               int64_t M, int N, int K, const float* bias, const float* img_bias,
               int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
-              float out_scale, unsigned flags, void* stream);
+              float out_scale, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * mimo_conv2d: channels-last implicit-GEMM convolution (3x3 or 1x1), MFMA.
@@ -104,7 +111,8 @@ typedef struct mimo_conv_params {
 
 int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
                 const mimo_conv_params* p, const float* bias, const float* img_bias,
-                const void* residual, float out_scale, unsigned flags, void* stream);
+                const void* residual, float out_scale, unsigned flags, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * GroupNorm (per image, 32 groups typical) over a *virtual channel concat* of two

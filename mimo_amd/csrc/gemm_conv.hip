@@ -40,6 +40,8 @@ struct GemmArgs {
   float out_scale;
   unsigned flags;
   int tiles_n;
+  void* ws;            // split-K workspace (fp32 partial tiles), may be null
+  size_t ws_bytes;
   // conv geometry
   int Hin, Win, Cin, Hout, Wout, ks, stride, pad_t, pad_l, Hup, Wup, Cin2;
   float sh, sw;
@@ -147,13 +149,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   const i32x4 rW = make_rsrc(g.W, g.w_bytes);
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
 
-  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= nkt: all-zero DMAs keep the counts uniform)
+  // split-K: gridDim.y blocks share one output tile, block y reduces K-tiles [kt_lo, kt_hi) into its own fp32
+  // partial (the launcher points g.out at the workspace); gridDim.y == 1 is the ordinary case
+  const int kt_lo = (int)(((int64_t)g.nkt * blockIdx.y) / gridDim.y);
+  const int kt_hi = (int)(((int64_t)g.nkt * (blockIdx.y + 1)) / gridDim.y);
+
+  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= kt_hi: all-zero DMAs keep the counts uniform)
   auto load_tile = [&](int kt, int slot) {
     // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
     unsigned offA[NAJ], kw = 0;
     bool cok = false;
     bool main_tap = true;
-    const bool live = kt < g.nkt;
+    const bool live = kt < kt_hi;
     if (CONV) {
       const int ntap_tiles = g.ks * g.ks * g.chunks1;
       main_tap = kt < ntap_tiles;
@@ -248,13 +255,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
     if (mfma_on) compute(slot_c, 1);
   };
 
-  const int nkt = g.nkt;
 #pragma unroll
-  for (int i = 0; i < NSTAGE - 1; ++i) load_tile(i, i);
-  for (int kt = 0; kt < nkt; kt += NSTAGE) {
+  for (int i = 0; i < NSTAGE - 1; ++i) load_tile(kt_lo + i, i);
+  for (int kt = kt_lo; kt < kt_hi; kt += NSTAGE) {
     step(IC<0>{}, kt);
-    if (kt + 1 < nkt) step(IC<1 % NSTAGE>{}, kt + 1);
-    if (NSTAGE > 2 && kt + 2 < nkt) step(IC<2 % NSTAGE>{}, kt + 2);
+    if (kt + 1 < kt_hi) step(IC<1 % NSTAGE>{}, kt + 1);
+    if (NSTAGE > 2 && kt + 2 < kt_hi) step(IC<2 % NSTAGE>{}, kt + 2);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 
@@ -271,7 +277,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   const int n_out = geglu ? g.N / 2 : g.N;
   const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-      (char*)g.out + M0 * g.ldo * esz_o, 0, (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
+      (char*)g.out + ((int64_t)blockIdx.y * g.M + M0) * g.ldo * esz_o, 0,
+      (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
       (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
       g.res ? (int)(((rows_valid - 1) * g.ldr + n_out) * esz_r) : 0, 0x00020000);
@@ -363,17 +370,65 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
 }
 
+// Split-K reduction + the full epilogue: out = epi(sum_s partial[s]); one thread per 4 consecutive columns.
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, int splits) {
+  const int n4 = g.N >> 2;
+  const int64_t total = g.M * n4;
+  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32, res_f32 = g.flags & MIMO_EPI_RES_F32, do_silu = g.flags & MIMO_EPI_SILU;
+  const float* ws = (const float*)g.ws;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / n4;
+    const int n = (int)(i - m * n4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(ws + m * g.N + n);
+    for (int s = 1; s < splits; ++s) {  // fixed order: deterministic
+      const float4 p = *reinterpret_cast<const float4*>(ws + ((int64_t)s * g.M + m) * g.N + n);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (g.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (g.img_bias) {
+      const float4 b = *reinterpret_cast<const float4*>(g.img_bias + (m / g.rows_per_img) * g.ldib + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (do_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    if (g.res) {
+      if (res_f32) {
+        const float4 r = *reinterpret_cast<const float4*>((const float*)g.res + m * g.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      } else {
+        const uint2 r = *reinterpret_cast<const uint2*>((const uint16_t*)g.res + m * g.ldr + n);
+        v.x += HT<DT>::to_f((uint16_t)(r.x & 0xffffu)); v.y += HT<DT>::to_f((uint16_t)(r.x >> 16));
+        v.z += HT<DT>::to_f((uint16_t)(r.y & 0xffffu)); v.w += HT<DT>::to_f((uint16_t)(r.y >> 16));
+      }
+    }
+    v.x *= g.out_scale; v.y *= g.out_scale; v.z *= g.out_scale; v.w *= g.out_scale;
+    if (out_f32) {
+      *reinterpret_cast<float4*>((float*)g.out + m * g.ldo + n) = v;
+    } else {
+      uint2 o;
+      o.x = pack2<DT>(v.x, v.y);
+      o.y = pack2<DT>(v.z, v.w);
+      *reinterpret_cast<uint2*>((uint16_t*)g.out + m * g.ldo + n) = o;
+    }
+  }
+}
+
 // Tuning knobs, read from the environment once (mimo_reload_tuning() re-reads them; tools/microbench.py --ab):
 //   MIMO_GEMM_CFG=1|2|3|4   force tile configuration S|L|XL|XL8
 //   MIMO_GEMM_STAGGER=0     all waves issue their DMAs right after the barrier (default 1: staggered)
 //   MIMO_CONV_TAP_INNER=0   convolution K order tap-outer / channel-chunk-inner (default 1: tap inner)
+//   MIMO_GEMM_SPLITK=0      never split K (default 1: long-K problems with too few tiles for the chip are split)
 //   MIMO_GEMM_ABLATE=1|2|3  timing experiments: skip DMA | skip MFMA | skip GELU (results are wrong)
 struct Tuning {
-  int cfg, ablate, stagger, tap_inner;
+  int cfg, ablate, stagger, tap_inner, splitk;
 };
 Tuning read_tuning() {
   auto env = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
-  return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1)};
+  return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1),
+                env("MIMO_GEMM_SPLITK", 1)};
 }
 Tuning& tuning() {
   static Tuning t = read_tuning();
@@ -404,6 +459,35 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   if (tn.stagger) g.flags |= 0x40000u;
   if (tn.tap_inner && MODE != 0) g.flags |= 0x80000u;
   if (cfg == 3 && NR == 5) cfg = 4;  // 16 waves x 128 registers cannot hold a 64 x 80 accumulator tile plus the epilogue
+  // Split-K: a long reduction over few output tiles (the 8x8-level convolutions: M = 3072, K = 11520) leaves most of
+  // the chip idle.  Use XL8 tiles, split K over gridDim.y, and let a second tiny launch reduce the fp32 partials
+  // (fixed order) and apply the epilogue.  Needs the caller's workspace.
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  if (forced == 0 && tn.splitk && !geglu && g.ws && NR == 5) {
+    const int64_t nt = m256 * tn_xl;
+    int64_t sk = nt > 0 ? cus / nt : 0;
+    if (sk > g.nkt / 16) sk = g.nkt / 16;
+    if (sk > 8) sk = 8;
+    const size_t need = (size_t)sk * (size_t)g.M * (size_t)g.N * sizeof(float);
+    if (sk >= 2 && nt * 2 <= cus && need <= g.ws_bytes) {
+      GemmArgs gp = g;
+      gp.tiles_n = tn_xl;
+      gp.out = g.ws; gp.ldo = g.N; gp.bias = nullptr; gp.img_bias = nullptr; gp.res = nullptr; gp.out_scale = 1.f;
+      gp.flags = (g.flags & 0xffff0000u) | MIMO_EPI_OUT_F32;
+      hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nt, (unsigned)sk), dim3(512), 0, st, gp);
+      MIMO_LAUNCH_CHECK();
+      int64_t rb = (g.M * (g.N >> 2) + 255) / 256;
+      if (rb > 4096) rb = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3((unsigned)rb), dim3(256), 0, st, g, (int)sk);
+      MIMO_LAUNCH_CHECK();
+      return MIMO_OK;
+    }
+  }
   if (cfg == 4) {  // XL8: the XL tile on 8 waves (2 x 4), each wave 128 x 16NR with a 256-register budget
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
@@ -447,7 +531,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
                          int64_t M, int N, int K, const float* bias, const float* img_bias,
                          int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
-                         float out_scale, unsigned flags, void* stream) {
+                         float out_scale, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return MIMO_EINVAL;
   if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out))
     return MIMO_EINVAL;
@@ -460,6 +544,7 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
   g.lda = lda; g.ldw = K; g.ldo = ldo; g.ldr = ldr; g.M = M; g.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
   g.ldib = img_bias_ld > 0 ? img_bias_ld : N;
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
+  g.ws = aligned16(workspace) ? workspace : nullptr; g.ws_bytes = workspace_bytes;
   g.nkt = (K + BK - 1) / BK;
   const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
   if (ab >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;  // operands are addressed with 32-bit offsets
@@ -472,7 +557,8 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
 
 extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
                            const mimo_conv_params* p, const float* bias, const float* img_bias,
-                           const void* residual, float out_scale, unsigned flags, void* stream) {
+                           const void* residual, float out_scale, unsigned flags, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   if (!in || !W || !out || !p) return MIMO_EINVAL;
   if (p->n <= 0 || p->Cin <= 0 || (p->Cin & 7) || (p->Cout & 3) || p->Cout <= 0) return MIMO_EINVAL;
   if (!(p->ksize == 1 || p->ksize == 3) || !(p->stride == 1 || p->stride == 2)) return MIMO_EINVAL;
@@ -490,6 +576,7 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.ldib = p->img_bias_ld > 0 ? p->img_bias_ld : p->Cout;
   if (g.ldib & 3) return MIMO_EINVAL;
   g.out_scale = out_scale; g.flags = flags;
+  g.ws = aligned16(workspace) ? workspace : nullptr; g.ws_bytes = workspace_bytes;
   g.Hin = p->Hin; g.Win = p->Win; g.Cin = p->Cin; g.Hout = p->Hout; g.Wout = p->Wout;
   g.ks = p->ksize; g.stride = p->stride; g.pad_t = p->pad_t; g.pad_l = p->pad_l;
   g.Hup = p->Hup; g.Wup = p->Wup; g.Cin2 = p->Cin2;
@@ -510,7 +597,9 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   return MIMO_EDTYPE;
 }
 
-extern "C" int mimo_version(void) { return 3; }
+extern "C" int mimo_version(void) { return 4; }
+
+extern "C" size_t mimo_workspace_bytes(void) { return (size_t)8 * ((size_t)1 << 22) * sizeof(float); }
 
 extern "C" int mimo_reload_tuning(void) {
   tuning() = read_tuning();

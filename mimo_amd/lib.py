@@ -14,6 +14,7 @@ F16, BF16 = 0, 1
 EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32 = 1, 2, 4, 8
 
 c_vp, c_i, c_i64, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint
+c_sz = ctypes.c_size_t
 
 
 class ConvParams(ctypes.Structure):
@@ -26,8 +27,10 @@ class ConvParams(ctypes.Structure):
 SIGNATURES = {
     "mimo_version": [],
     "mimo_reload_tuning": [],
-    "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp],
-    "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp],
+    "mimo_workspace_bytes": [],
+    "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp,
+                  c_sz, c_vp],
+    "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
     "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp],
@@ -51,6 +54,9 @@ class MimoHipError(RuntimeError):
 _lib = None
 
 
+RESTYPES = {"mimo_workspace_bytes": c_sz}  # every other entry point returns int (0 or an error code)
+
+
 def load():
     """Load the shared library (once) and declare every prototype."""
     global _lib
@@ -64,7 +70,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = c_i
+        fn.restype = RESTYPES.get(name, c_i)
     _lib = lib
     return lib
 

@@ -61,6 +61,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_WS = {}
+
+
+def _workspace(device):
+    """Split-K scratch handed to mimo_gemm / mimo_conv2d (include/mimo_hip.h, workspace convention): one fp32
+    buffer per (device, stream), reused by every launch (launches on one stream are ordered, so sharing is safe)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(L.load().mimo_workspace_bytes() // 4, device=device, dtype=torch.float32)
+    return ws
+
+
 def _chk(t, name):
     if not t.is_cuda:
         raise L.MimoHipError(f"{name} must be a device tensor: mimo_amd has no CPU path")
@@ -100,9 +113,10 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
         ldib = img_bias.stride(0)
     _count(2 * M * N * K)
     with _Bracket("gemm_kernel", 2 * M * N * K):
+        ws = _workspace(a.device)
         L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
                out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
-               float(out_scale), flags, _stream())
+               float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, _stream())
     return out
 
 
@@ -142,8 +156,10 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
     fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
     _count(fl)
     with _Bracket("gemm_kernel", fl):
+        ws = _workspace(x.device)
         L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
-               ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags, _stream())
+               ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags,
+               ws.data_ptr(), ws.numel() * 4, _stream())
     return out
 
 

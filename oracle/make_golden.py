@@ -2,11 +2,13 @@
 (/root/reference/src behind oracle/diffusers_standin.py, CPU fp32) on seeded synthetic weights and inputs.
 Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, same torch CPU generator).
 
-    python -m oracle.make_golden [small] [forward512] [config1]
+    python -m oracle.make_golden [small] [forward512] [config1] [config2]
 
   small       half-width UNets (4 heads, d = 40/80/160): denoising forward + banks, odd-size forward
   forward512  FULL-SIZE denoising UNet, config-2 shapes: one forward on 2 x 24 latent frames 64x64 (about 4 min, 15 GB)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
+  config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
+              0, 4, 9, 14, 19; about 50 min and 16 GB on 8 cores)
 """
 import os
 import sys
@@ -89,10 +91,19 @@ def forward512():
 
 
 def config1():
-    """BASELINE configs[0]: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 through the reference's own Pose2VideoPipeline."""
+    """BASELINE configs[0]: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 through the reference's own models."""
+    _clip(256, 8, 4, range(4), "config1_256_8f_4steps.safetensors")
+
+
+def config2():
+    """BASELINE configs[1] (the bench workload): 512x512, 24 frames (one context window), 20 DDIM steps, CFG 3.5."""
+    _clip(512, 24, 20, (0, 4, 9, 14, 19), "config2_512_24f_20steps.safetensors")
+
+
+def _clip(size, F, steps, keep, fname):
     from src.pipelines.pipeline_pose2vid_long_edit_bkfill_roiclip import Pose2VideoPipeline
     import src.models.pose_guider as pg
-    r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, 32, 1234, 1235)
+    r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, size // 8, 1234, 1235)
     opg = synth.build(OM.PoseGuider, 1236)
     rpg = pg.PoseGuider(320, 3, (16, 32, 96, 256)).eval()
     rpg.load_state_dict(opg.state_dict())
@@ -108,8 +119,8 @@ def config1():
     # equal to Pose2VideoPipeline.__call__).
     import src.models.mutual_self_attention as msa
     from .pipeline import uniform
-    H = W = 256
-    F, steps, gs = 8, 4, 3.5
+    H = W = size
+    gs = 3.5
     g = torch.Generator().manual_seed(11)
     ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     bk = torch.ones(F, 3, H, W)
@@ -135,11 +146,12 @@ def config1():
             pred = r3(x, t, encoder_hidden_states=ehs, pose_cond_fea=pose_fea.repeat(2, 1, 1, 1, 1), return_dict=False)[0]
             un, co = pred.chunk(2)
             lat = sched.step(un + gs * (co - un), t, lat, eta=0.0).prev_sample
-            traj[f"latents_step{i}"] = lat.clone()
-            print("step", i, int(t), flush=True)
+            if i in keep:
+                traj[f"latents_step{i}"] = lat.clone()
+            print("step", i, int(t), time.strftime("%H:%M:%S"), flush=True)
     traj["ref_latents"] = ref_lat
     traj["pose_fea_frame0"] = pose_fea[:, :, 0].contiguous()
-    save_file(traj, os.path.join(OUT, "config1_256_8f_4steps.safetensors"))
+    save_file(traj, os.path.join(OUT, fname))
 
 
 if __name__ == "__main__":
@@ -147,4 +159,4 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ["small"]
     for w in what:
-        {"small": small, "forward512": forward512, "config1": config1}[w]()
+        {"small": small, "forward512": forward512, "config1": config1, "config2": config2}[w]()

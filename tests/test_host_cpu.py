@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     path = build.build()
     assert os.path.exists(path)
     header = open(os.path.join(ROOT, "include", "mimo_hip.h")).read()
-    declared = set(re.findall(r"^int (mimo_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t) (mimo_\w+)\(", header, flags=re.M))
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     cdll = lib.load()
     for name in declared:

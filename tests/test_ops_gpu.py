@@ -148,6 +148,52 @@ def test_conv2d_resblock_epilogue_and_fused_shortcut(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_split_k_long_reduction_few_tiles(dev, dtype):
+    """Few output tiles + long K (the 8x8-level ResBlock convs, M = 48*64, K = 9*1280+640) take the split-K route:
+    fp32 partial tiles in the caller's workspace, reduced in fixed order with the full epilogue.  Checked against
+    the unsplit kernels (MIMO_GEMM_SPLITK=0) bit-for-bit-close and against the fp32 reference."""
+    import os
+    from mimo_amd import lib as L, ops
+    from mimo_amd.packing import pack_conv
+    n, H, W, cin, cout, cx = 48, 8, 8, 1280, 1280, 640
+    h = rnd((n, H, W, cin), dev, dtype, 1)
+    x = rnd((n, H, W, cx), dev, dtype, 2)
+    w = rnd((cout, cin, 3, 3), dev, dtype, 3, (9 * cin) ** -0.5)
+    ws = rnd((cout, cx, 1, 1), dev, dtype, 4, cx ** -0.5)
+    b = rnd((cout,), dev, torch.float32, 5)
+    temb = rnd((2, cout), dev, torch.float32, 6)
+    res = rnd((n, H, W, cout), dev, torch.float32, 7)
+    wp = pack_conv(w, dtype, shortcut=ws)
+    ref = torch_conv_ref(h, w, b, 3, 1, None, None, None) + \
+        F.conv2d(x.float().permute(0, 3, 1, 2), ws.float()).permute(0, 2, 3, 1) + \
+        temb.repeat_interleave(24, 0)[:, None, None, :] + res
+
+    def run():
+        o1 = ops.conv2d(h, wp, cout, x2=x, bias=b, img_bias=temb, imgs_per_bias_row=24, residual=res, out_f32=True)
+        o2 = ops.conv2d(h, wp, cout, x2=x, bias=b, silu=True, out_scale=0.5)
+        a = h.view(-1, cin)[:, :]
+        wl = rnd((1280, cin), dev, dtype, 9, cin ** -0.5)
+        a4 = torch.cat([a, a, a, a], dim=1)                      # K = 5120
+        w4 = torch.cat([wl, wl, wl, wl], dim=1).contiguous()
+        o3 = ops.gemm(a4, w4, bias=b, residual=res.view(-1, cout).to(dtype))
+        return o1, o2, o3, a4, w4
+
+    try:
+        os.environ["MIMO_GEMM_SPLITK"] = "0"
+        L.call("mimo_reload_tuning")
+        u1, u2, u3, a4, w4 = run()
+    finally:
+        os.environ.pop("MIMO_GEMM_SPLITK", None)
+        L.call("mimo_reload_tuning")
+    s1, s2, s3, _, _ = run()
+    assert rel_l2(s1, ref) < ACC_TOL and rel_l2(s1, u1) < 1e-5
+    assert rel_l2(s2.float(), u2.float()) < OUT_TOL[dtype]
+    assert rel_l2(s2.float(), 0.5 * F.silu(ref - temb.repeat_interleave(24, 0)[:, None, None, :] - res)) < OUT_TOL[dtype]
+    ref3 = a4.float() @ w4.float().t() + b + res.view(-1, cout).to(dtype).float()
+    assert rel_l2(s3.float(), ref3) < OUT_TOL[dtype] and rel_l2(s3.float(), u3.float()) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("f32in", [True, False])
 @pytest.mark.parametrize("C1,C2,eps,silu", [(320, 0, 1e-5, True), (1280, 640, 1e-5, True), (320, 640, 1e-6, False), (128, 0, 1e-6, True)])
 def test_group_norm_concat(dev, dtype, f32in, C1, C2, eps, silu):
