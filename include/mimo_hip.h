@@ -133,14 +133,14 @@ int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_
                           const float* beta, int silu, void* out, void* raw_out, void* stream);
 
 /* ---------------------------------------------------------------------------------
- * LayerNorm over the last dim of x [rows, C] (fp32 or half16) -> half16, optional
+ * LayerNorm over the last dim of x [rows, C] (fp32 or half16) -> half16 `out` and / or fp32 `out_f32`, optional
  * additive positional table pe[(row / rows_per_frame) % pe_frames, C] (fp32).
  *   replaces nn.LayerNorm (src/models/attention.py:329-360; src/models/motion_module.py:230-258)
  *   and PositionalEncoding.forward (src/models/motion_module.py:276-279).
  * --------------------------------------------------------------------------------- */
 int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C, float eps,
                     const float* gamma, const float* beta, const float* pe, int64_t rows_per_frame,
-                    int pe_frames, void* out, void* stream);
+                    int pe_frames, void* out, float* out_f32, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const void* x, int f32,
                                                          float eps, const float* gamma,
                                                          const float* beta, const float* pe,
                                                          int64_t rows_per_frame, int pe_frames,
-                                                         uint16_t* out) {
+                                                         uint16_t* out, float* out32) {
   const int lane = threadIdx.x & 63;
   const int c8 = C / 8;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -337,7 +337,11 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const void* x, int f32,
           y[0] += pa.x; y[1] += pa.y; y[2] += pa.z; y[3] += pa.w;
           y[4] += pb.x; y[5] += pb.y; y[6] += pb.z; y[7] += pb.w;
         }
-        *reinterpret_cast<uint4*>(out + row * C + ci * 8) = pack8<DT>(y);
+        if (out) *reinterpret_cast<uint4*>(out + row * C + ci * 8) = pack8<DT>(y);
+        if (out32) {
+          *reinterpret_cast<float4*>(out32 + row * C + ci * 8) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(out32 + row * C + ci * 8 + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
       }
     }
 #pragma unroll
@@ -452,8 +456,8 @@ extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int
 
 extern "C" int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C, float eps,
                                const float* gamma, const float* beta, const float* pe,
-                               int64_t rows_per_frame, int pe_frames, void* out, void* stream) {
-  if (!x || !out || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 2048) return MIMO_EINVAL;
+                               int64_t rows_per_frame, int pe_frames, void* out, float* out_f32, void* stream) {
+  if (!x || (!out && !out_f32) || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 2048) return MIMO_EINVAL;
   if (pe && (rows_per_frame <= 0 || pe_frames <= 0)) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int64_t nb = (rows + 3) / 4;
@@ -462,7 +466,7 @@ extern "C" int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t r
   const int vpl = (C / 8 + 63) / 64;
 #define LN_LAUNCH(DT, V)                                                                              \
   hipLaunchKernelGGL((layer_norm_kernel<DT, V>), dim3(grid), dim3(256), 0, st, x, x_is_f32, rows, C, \
-                     eps, gamma, beta, pe, rows_per_frame, pe_frames, (uint16_t*)out)
+                     eps, gamma, beta, pe, rows_per_frame, pe_frames, (uint16_t*)out, out_f32)
   if (dtype == MIMO_F16) {
     if (vpl == 1) LN_LAUNCH(MIMO_F16, 1); else if (vpl == 2) LN_LAUNCH(MIMO_F16, 2);
     else if (vpl == 3) LN_LAUNCH(MIMO_F16, 3); else LN_LAUNCH(MIMO_F16, 4);

@@ -33,7 +33,7 @@ SIGNATURES = {
     "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
-    "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp],
+    "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp],
     "mimo_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],

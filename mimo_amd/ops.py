@@ -205,17 +205,18 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
     return out, raw
 
 
-def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0):
-    """LayerNorm over the last dim of x [rows, C] -> half; optional + pe[(row // rows_per_frame) % pe_frames]."""
+def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0, out_f32=False):
+    """LayerNorm over the last dim of x [rows, C] -> half (fp32 if out_f32); optional + pe[(row // rows_per_frame) % pe_frames]."""
     _chk(x, "x")
     assert x.is_contiguous()
     C = x.shape[-1]
     rows = x.numel() // C
     if dtype is None:
         dtype = x.dtype if x.dtype in _DT else torch.float16
-    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32 if out_f32 else dtype)
     L.call("mimo_layer_norm", x.data_ptr(), _is_f32(x), dt_code(dtype), rows, C, float(eps), gamma.data_ptr(),
-           beta.data_ptr(), _ptr(pe), rows_per_frame, pe_frames, out.data_ptr(), _stream())
+           beta.data_ptr(), _ptr(pe), rows_per_frame, pe_frames, None if out_f32 else out.data_ptr(),
+           out.data_ptr() if out_f32 else None, _stream())
     return out
 
 

@@ -133,3 +133,39 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
     errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in range(4)]
     print("config-1 latents rel_l2 per step:", ["%.2e" % e for e in errs])
     assert errs[0] < 1e-3 and errs[-1] < 3e-3  # one forward: 1e-3; four chained forwards accumulate
+
+
+@pytest.mark.gpu
+def test_hip_config2_pipeline_vs_reference_golden(full_models):
+    """BASELINE configs[1] — the bench workload: 512x512, 24 frames, 20 DDIM steps, CFG 3.5, full-size models, VAE encode +
+    pose guider + reference UNet + 20 denoising forwards, against the reference's own code on CPU fp32 (about 50 min
+    there, oracle/make_golden.py config2).  Latents after steps 0, 4, 9, 14 and 19."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_512_24f_20steps.safetensors")
+    if not os.path.exists(path):
+        pytest.skip("config-2 golden fixture not generated")
+    G = gold("config2_512_24f_20steps.safetensors")
+    dev = torch.device("cuda:0")
+    H = W = 512
+    F = 24
+    g = torch.Generator().manual_seed(11)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.ones(F, 3, H, W)
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    m = full_models
+    pipe = Pose2VideoPipeline(m["vae"], None, m["ref"], m["den"], m["pose"], DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    traj = []
+    video = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 20, 3.5, trajectory=traj)
+    assert video.shape == (1, 3, F, H, W) and bool(torch.isfinite(video).all())
+    keep = (0, 4, 9, 14, 19)
+    errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in keep]
+    line = "config-2 (512x512, 24 f, 20 steps) latents rel_l2 at steps 0/4/9/14/19: " + " ".join("%.2e" % e for e in errs)
+    print(line)
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt"), "a") as f:
+        f.write(line + "\n")
+    assert errs[0] < 1e-3 and max(errs) < 5e-3  # one forward: 1e-3; chained forwards accumulate operand rounding

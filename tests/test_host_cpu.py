@@ -137,3 +137,18 @@ def test_exchange_predictions_world2_gloo():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+def test_clip_image_encoder_state_dict_matches_transformers():
+    """mimo_amd.clip mirrors transformers.CLIPVisionModelWithProjection key for key (ViT-L/14 shapes on the meta device)."""
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                           image_size=224, patch_size=14, projection_dim=768)
+    with torch.device("meta"):
+        ref, prod = RefCLIP(cfg), CLIPVisionModelWithProjection(cfg)
+    rs = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.endswith("position_ids")}
+    ps = {k: tuple(v.shape) for k, v in prod.state_dict().items()}
+    assert rs == ps
+    assert sum(v.numel() for v in prod.parameters()) == sum(v.numel() for v in ref.parameters())

@@ -214,3 +214,44 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W)
     assert e_lat < {torch.float16: 3e-3, torch.bfloat16: 3e-2}[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("size", ["small", "vit_l_14"])
+def test_clip_image_encoder_vs_transformers(dev, dtype, size):
+    """SURVEY 8(f) rank 1.  Oracle = the reference's own dependency, transformers' CLIPVisionModelWithProjection, on CPU
+    fp32 with seeded random weights (norm affine parameters perturbed so they are not numerically invisible)."""
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    if size == "small":
+        cfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                               image_size=56, patch_size=14, projection_dim=96)
+    else:
+        if dtype == torch.bfloat16:
+            pytest.skip("full ViT-L/14 tower: fp16 run only")
+        cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                               image_size=224, patch_size=14, projection_dim=768)
+    torch.manual_seed(77)
+    ref = RefCLIP(cfg).eval()
+    g = torch.Generator().manual_seed(78)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.copy_((1.0 if n.endswith("weight") else 0.0) + 0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    prod = CLIPVisionModelWithProjection(cfg)
+    missing, unexpected = prod.load_state_dict(ref.state_dict(), strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+    prod.to(dev)
+    prod.compute_dtype = dtype
+    B = 2 if size == "small" else 1
+    x = torch.randn(B, 3, cfg.image_size, cfg.image_size, generator=g)
+    with torch.no_grad():
+        r = ref(pixel_values=x)
+    o = prod(x.to(dev))
+    e1 = rel_l2(o.image_embeds.float().cpu(), r.image_embeds)
+    e2 = rel_l2(o.last_hidden_state.float().cpu(), r.last_hidden_state)
+    report(f"clip image encoder {size} {dtype}: image_embeds rel_l2={e1:.2e} last_hidden rel_l2={e2:.2e}")
+    assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
