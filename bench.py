@@ -58,18 +58,20 @@ def build_pipeline(dev, dtype, seed=1234):
     from mimo_amd.scheduler import DDIMScheduler
     from mimo_amd.unet import UNet2DConditionModel, UNet3DConditionModel
     from mimo_amd.vae import AutoencoderKL, PoseGuider
+    from mimo_amd.clip import CLIPVisionModelWithProjection
     torch.manual_seed(seed)
     with torch.device(dev):  # parameters are initialised directly in HBM
         den = UNet3DConditionModel()
         ref = UNet2DConditionModel()
         vae = AutoencoderKL()
         pg = PoseGuider()
-    for i, m in enumerate((den, ref, vae, pg)):
+        clip = CLIPVisionModelWithProjection()  # ViT-L/14 vision tower + projection (pretrained_weights/image_encoder)
+    for i, m in enumerate((den, ref, vae, pg, clip)):
         randomize_(m, seed + 1 + i)
         m.to(dtype=dtype)  # weights held in the compute dtype, like the reference's weight_dtype
         m.compute_dtype = dtype
         m.requires_grad_(False)
-    return Pose2VideoPipeline(vae, None, ref, den, pg, DDIMScheduler(**NOISE_SCHEDULER_KWARGS))
+    return Pose2VideoPipeline(vae, clip, ref, den, pg, DDIMScheduler(**NOISE_SCHEDULER_KWARGS))
 
 
 def synthetic_inputs(dev, frames, size, seed):
@@ -79,6 +81,7 @@ def synthetic_inputs(dev, frames, size, seed):
                 bk_images=torch.ones(frames, 3, size, size, device=dev),  # run_animate: white background (tools/util.py:339-345)
                 pose_images=torch.rand(frames, 3, size, size, generator=g).to(dev),
                 clip_embeds=torch.randn(1, 768, generator=g).to(dev),
+                clip_pixels=torch.randn(1, 3, 224, 224, generator=g).to(dev),  # CLIPImageProcessor output of the reference image
                 latents=torch.randn(1, 4, frames, h, h, generator=g).to(dev))
 
 
@@ -215,7 +218,10 @@ def main():
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
 
     def clip():
-        return pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], inp["clip_embeds"],
+        # the whole __call__ body on device: CLIP image embedding, VAE encodes, pose guider, reference UNet,
+        # the denoising loop, VAE decode (pipeline_pose2vid_long_edit_bkfill_roiclip.py:379-578)
+        emb = pipe.image_encoder(inp["clip_pixels"].to(dtype)).image_embeds
+        return pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], emb,
                                 inp["latents"], a.ddim_steps, a.guidance)
 
     def barrier():
@@ -255,7 +261,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {a.size}x{a.size}, {a.frames}-frame clip per GPU, {a.ddim_steps} DDIM steps, "
-                                   f"CFG {a.guidance}, reference_unet + pose_guider + VAE enc/dec inside the timed region; "
+                                   f"CFG {a.guidance}, CLIP image encoder + reference_unet + pose_guider + VAE enc/dec inside the timed region; "
                                    + ("one long clip, (window x CFG-half) units sharded, all_gather per step" if a.shard_windows
                                       else "independent clip per GPU, no collective"),
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),

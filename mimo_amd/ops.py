@@ -61,6 +61,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def set_split_k(enabled):
+    """Split-K changes the fp32 summation order of a long reduction as a function of the row count M, i.e. of the
+    batch size.  Runs that must be bit-identical across batch decompositions (one long clip sharded over ranks vs
+    the same clip on one GPU) switch it off on both sides; the default (on) is the faster single-GPU setting."""
+    import os
+    os.environ["MIMO_GEMM_SPLITK"] = "1" if enabled else "0"
+    L.call("mimo_reload_tuning")
+
+
 _WS = {}
 
 

@@ -47,6 +47,24 @@ def plan_units(num_windows, cfg, rank, world):
     return units, [u for i, u in enumerate(units) if i % world == rank]
 
 
+def sharded_frames(fn, x, rank, world, group=None):
+    """Per-frame stage (VAE encode / decode, pose guider) over frames [F, ...] with the frames dealt in contiguous
+    chunks over the ranks: every rank runs `fn` on its chunk only, one all_gather rebuilds the full result on every
+    rank.  Per-frame ops are independent of the batch they run in, so the result equals the unsharded call."""
+    import torch.distributed as dist
+    F = x.shape[0]
+    per = math.ceil(F / world)
+    lo, hi = min(F, rank * per), min(F, (rank + 1) * per)
+    # a rank past the end (F < world * per) still joins the collective with a dummy frame
+    mine = fn(x[lo:hi] if hi > lo else x[:1])
+    send = torch.zeros((per,) + tuple(mine.shape[1:]), device=mine.device, dtype=mine.dtype)
+    if hi > lo:
+        send[:hi - lo] = mine
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    return torch.cat(recv, 0)[:F].contiguous()
+
+
 def exchange_predictions(my_preds, units, rank, world, group=None):
     """all_gather of the per-unit prediction tensors (equal shapes).  Returns {unit: tensor} for ALL units.
     Ranks own ceil/floor(len(units)/world) units; short ranks pad with a zero tensor."""
@@ -116,6 +134,7 @@ class Pose2VideoPipeline:
         self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
+        self.batch_invariant = False  # True: bit-identical to the sharded run of the same clip (split-K off)
         self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
         self.stage_times = None     # dict -> accumulates per-stage milliseconds (HIP events) of run_tensors
         self._graphs = {}
@@ -172,6 +191,8 @@ class Pose2VideoPipeline:
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             import torch.distributed as dist
             rank, world = dist.get_rank(self.dist_group), dist.get_world_size(self.dist_group)
+        if world > 1 or self.batch_invariant:
+            ops.set_split_k(False)  # summation order must not depend on how the clip is cut into batches
         sched.set_timesteps(num_inference_steps)
         latents = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
         _, C, F, h, w = latents.shape
@@ -190,10 +211,18 @@ class Pose2VideoPipeline:
 
         mark("start")
         ref_lat = self._encode_frames(ref_image.to(dev).float())               # [1,h,w,4]
-        bk_tok = self._encode_frames(bk_images.to(dev).float()).to(dt)         # [F,h,w,4]
-        pose_in = ops.ncfhw_to_tokens(pose_images.to(dev).float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
-        pose_tok = torch.cat([self.pose_guider.run_tokens(pose_in[i:i + self.vae_batch].contiguous())
-                              for i in range(0, F, self.vae_batch)])          # fp32 [F,h,w,C0]
+
+        def pose_fn(frames):
+            tok = ops.ncfhw_to_tokens(frames.contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
+            return torch.cat([self.pose_guider.run_tokens(tok[i:i + self.vae_batch].contiguous())
+                              for i in range(0, tok.shape[0], self.vae_batch)])
+
+        if world > 1:  # one long clip over the ranks: the per-frame stages are sharded too
+            bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev).float(), rank, world, self.dist_group).to(dt)
+            pose_tok = sharded_frames(pose_fn, pose_images.to(dev).float(), rank, world, self.dist_group)
+        else:
+            bk_tok = self._encode_frames(bk_images.to(dev).float()).to(dt)     # [F,h,w,4]
+            pose_tok = pose_fn(pose_images.to(dev).float())                    # fp32 [F,h,w,C0]
 
         # reference UNet at t = 0 (pipeline :480-490): only the cond element's banks are ever read, and
         # everything after the last bank write is dead code -> run b = 1 with early exit.
@@ -259,7 +288,12 @@ class Pose2VideoPipeline:
         mark("denoising_loop")
         if not decode:
             return latents
-        video = self._decode_frames(latents)
+        if world > 1:
+            fr = sharded_frames(lambda z: self._decode_frames(z.permute(1, 0, 2, 3)[None].contiguous())[0].permute(1, 0, 2, 3),
+                                latents[0].permute(1, 0, 2, 3).contiguous(), rank, world, self.dist_group)
+            video = fr.permute(1, 0, 2, 3)[None].contiguous()
+        else:
+            video = self._decode_frames(latents)
         mark("vae_decode")
         if self.stage_times is not None:
             torch.cuda.synchronize()

@@ -152,3 +152,33 @@ def test_clip_image_encoder_state_dict_matches_transformers():
     ps = {k: tuple(v.shape) for k, v in prod.state_dict().items()}
     assert rs == ps
     assert sum(v.numel() for v in prod.parameters()) == sum(v.numel() for v in ref.parameters())
+
+
+def _sharded_frames_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mimo_amd.pipeline import sharded_frames
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ok = True
+    for F in (1, 5, 8):  # F < world, ragged, even
+        x = torch.arange(F * 6, dtype=torch.float32).reshape(F, 2, 3)
+        fn = lambda t: (t * 2 + 1).sum(dim=1)  # a per-frame op: [f, 2, 3] -> [f, 3]
+        out = sharded_frames(fn, x, rank, world)
+        ok &= bool(torch.equal(out, fn(x)))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_frames_world2_gloo():
+    """Per-frame stages of the long-clip mode (VAE encode / decode, pose guider): contiguous frame chunks per rank +
+    one all_gather reproduce the unsharded result, including F < world and ragged F."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 500 + 7
+    procs = [ctx.Process(target=_sharded_frames_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p_ in procs:
+        p_.join(timeout=60)
+    assert res == [(0, True), (1, True)]
