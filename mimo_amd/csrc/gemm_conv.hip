@@ -420,15 +420,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, in
 //   MIMO_GEMM_CFG=1|2|3|4   force tile configuration S|L|XL|XL8
 //   MIMO_GEMM_STAGGER=0     all waves issue their DMAs right after the barrier (default 1: staggered)
 //   MIMO_CONV_TAP_INNER=0   convolution K order tap-outer / channel-chunk-inner (default 1: tap inner)
+//   MIMO_GEMM_BM=256|192|128  force the XL8 tile height (default: picked per shape by wave quantisation)
 //   MIMO_GEMM_SPLITK=0      never split K (default 1: long-K problems with too few tiles for the chip are split)
 //   MIMO_GEMM_ABLATE=1|2|3  timing experiments: skip DMA | skip MFMA | skip GELU (results are wrong)
 struct Tuning {
-  int cfg, ablate, stagger, tap_inner, splitk;
+  int cfg, ablate, stagger, tap_inner, splitk, bm;
 };
 Tuning read_tuning() {
   auto env = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
   return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1),
-                env("MIMO_GEMM_SPLITK", 1)};
+                env("MIMO_GEMM_SPLITK", 1), env("MIMO_GEMM_BM", 0)};
 }
 Tuning& tuning() {
   static Tuning t = read_tuning();
@@ -488,11 +489,26 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
       return MIMO_OK;
     }
   }
-  if (cfg == 4) {  // XL8: the XL tile on 8 waves (2 x 4), each wave 128 x 16NR with a 256-register budget
+  if (cfg == 4) {  // XL8: the XL tile on 8 waves (2 x 4), each wave (16 MT) x 16NR with a 256-register budget
+    // Tile height 256 | 192 | 128 rows (MT = 8 | 6 | 4): with one block per CU the launch runs in rounds of `cus`
+    // tiles, so pick the height that minimises rounds x (rows + per-tile overhead) — e.g. M = 12288, N = 1280 is
+    // 192 tiles of 256 rows (75 % of the chip for one round) but exactly 256 tiles of 192 rows.
     g.tiles_n = tn_xl;
-    const int64_t nwg = m256 * tn_xl;
+    auto cost = [&](int bm) {
+      const int64_t nt = ((g.M + bm - 1) / bm) * tn_xl;
+      return ((nt + cus - 1) / cus) * (int64_t)(bm + 24);
+    };
+    int bm = tn.bm;
+    if (bm != 256 && bm != 192 && bm != 128) {
+      bm = 256;
+      if (cost(192) < cost(bm)) bm = 192;
+      if (cost(128) < cost(bm)) bm = 128;
+    }
+    const int64_t nwg = ((g.M + bm - 1) / bm) * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    if (bm == 256) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    else if (bm == 192) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 6>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 4>), dim3((unsigned)nwg), dim3(512), 0, st, g);
   } else if (cfg == 3) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;

@@ -26,7 +26,7 @@ def timeit(fn, iters=10, warm=3):
 
 def ab_table(settings, dt, dev, n):
     """Interleaved A/B: every shape is timed under every knob setting in turn, 3 rounds, best median kept."""
-    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE")
+    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE", "MIMO_GEMM_BM")
     cases = []
     for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (8, 2560, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
@@ -35,12 +35,13 @@ def ab_table(settings, dt, dev, n):
         cases.append((f"conv3x3 {hw}x{hw} {cin}->{cout}", (lambda x=x, w=w, b=b, cout=cout: ops.conv2d(x, w, cout, bias=b, out_f32=True)),
                       2 * n * hw * hw * cout * 9 * cin))
     for (M, N, K) in [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (49152, 640, 2560),
+                      (49152, 1920, 640), (12288, 3840, 1280),
                       (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280), (3072, 1280, 5120)]:
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) * 0.02).to(dt)
         R = torch.randn(M, N, device=dev)
         cases.append((f"gemm M{M} N{N} K{K}", (lambda A=A, W=W: ops.gemm(A, W)), 2 * M * N * K))
-        if N == 320 or K == 2560:
+        if N in (320, 640, 1280) and M >= 12288:
             cases.append((f"gemm+res32 M{M} N{N} K{K}", (lambda A=A, W=W, R=R: ops.gemm(A, W, residual=R, out_f32=True)), 2 * M * N * K))
     for (M, dim) in [(196608, 320), (49152, 640), (12288, 1280)]:
         A = torch.randn(M, dim, device=dev).to(dt)
