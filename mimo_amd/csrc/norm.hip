@@ -176,23 +176,33 @@ template <int DT>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const void* x1, int C1, const void* x2, int C2, int f32,
                                                           int64_t HW, int groups, int total, float eps,
                                                           const float* partials, int split, float* stats) {
-  const int ig = blockIdx.x * 256 + threadIdx.x;
+  // one wave per (image, group): lane l adds partials l, l + 64, ... in double, then a fixed butterfly — the result
+  // depends on `split` only, never on scheduling
+  const int ig = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (ig >= total) return;
   const int img = ig / groups, grp = ig % groups;
   const int cpg = (C1 + C2) / groups, c0 = grp * cpg;
-  // the shift every slice used: the group's first element
-  const float sh = c0 < C1 ? load_elem<DT>(x1, f32, (int64_t)img * HW * C1 + c0)
-                           : load_elem<DT>(x2, f32, (int64_t)img * HW * C2 + (c0 - C1));
   double S = 0.0, Q = 0.0;
-  for (int k = 0; k < split; ++k) {
+  for (int k = lane; k < split; k += 64) {
     S += (double)partials[((int64_t)ig * split + k) * 2];
     Q += (double)partials[((int64_t)ig * split + k) * 2 + 1];
   }
-  const double n = (double)HW * cpg;
-  const double ms = S / n;
-  const double var = fmax(Q / n - ms * ms, 0.0);
-  stats[(int64_t)ig * 2 + 0] = sh + (float)ms;
-  stats[(int64_t)ig * 2 + 1] = rsqrtf((float)var + eps);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    S += __shfl_xor(S, o, 64);
+    Q += __shfl_xor(Q, o, 64);
+  }
+  if (lane == 0) {
+    // the shift every slice used: the group's first element
+    const float sh = c0 < C1 ? load_elem<DT>(x1, f32, (int64_t)img * HW * C1 + c0)
+                             : load_elem<DT>(x2, f32, (int64_t)img * HW * C2 + (c0 - C1));
+    const double n = (double)HW * cpg;
+    const double ms = S / n;
+    const double var = fmax(Q / n - ms * ms, 0.0);
+    stats[(int64_t)ig * 2 + 0] = sh + (float)ms;
+    stats[(int64_t)ig * 2 + 1] = rsqrtf((float)var + eps);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -401,7 +411,7 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
       hipLaunchKernelGGL(gn_stats_rows_kernel<MIMO_BF16>, dim3(rgrid), dim3(threads), lds, st, x1, C1, x2, C2, x_is_f32, HW, groups, partials, split);
     MIMO_LAUNCH_CHECK();
     const int total = n * groups;
-    const unsigned fg = (unsigned)((total + 255) / 256);
+    const unsigned fg = (unsigned)((total + 3) / 4);
     if (dtype == MIMO_F16)
       hipLaunchKernelGGL(gn_finalize_kernel<MIMO_F16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
     else
@@ -423,7 +433,7 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
   MIMO_LAUNCH_CHECK();
   if (split > 1) {
     const int total = n * groups;
-    const unsigned fg = (unsigned)((total + 255) / 256);
+    const unsigned fg = (unsigned)((total + 3) / 4);
     if (dtype == MIMO_F16)
       hipLaunchKernelGGL(gn_finalize_kernel<MIMO_F16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
     else

@@ -34,6 +34,12 @@ def ab_table(settings, dt, dev, n):
         b = torch.zeros(cout, device=dev)
         cases.append((f"conv3x3 {hw}x{hw} {cin}->{cout}", (lambda x=x, w=w, b=b, cout=cout: ops.conv2d(x, w, cout, bias=b, out_f32=True)),
                       2 * n * hw * hw * cout * 9 * cin))
+    for (nn, hw, cin, cout) in [(8, 512, 128, 128), (8, 256, 256, 256), (8, 128, 512, 512)]:  # VAE decoder convs
+        x = torch.randn(nn, hw, hw, cin, device=dev).to(dt)
+        w = pack_conv(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, dt)
+        b = torch.zeros(cout, device=dev)
+        cases.append((f"vae conv3x3 n{nn} {hw}x{hw} {cin}->{cout}", (lambda x=x, w=w, b=b, cout=cout: ops.conv2d(x, w, cout, bias=b, out_f32=True)),
+                      2 * nn * hw * hw * cout * 9 * cin))
     for (M, N, K) in [(196608, 320, 320), (196608, 960, 320), (196608, 320, 1280), (49152, 640, 640), (49152, 640, 2560),
                       (49152, 1920, 640), (12288, 3840, 1280),
                       (12288, 1280, 1280), (12288, 1280, 5120), (3072, 1280, 1280), (3072, 1280, 5120)]:
