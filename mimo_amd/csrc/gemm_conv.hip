@@ -40,6 +40,7 @@ struct GemmArgs {
   float out_scale;
   unsigned flags;
   int tiles_n;
+  unsigned ntiles;     // persistent kernels: number of output tiles
   void* ws;            // split-K workspace (fp32 partial tiles), may be null
   size_t ws_bytes;
   // conv geometry
@@ -57,6 +58,117 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- epilogue of one output tile: lane holds out[m = M0 + .. + li][n = N0 + .. + 4*lg + r], r = 0..3 ----
+template <int DT, int NR, int MT, int BM>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0, const int N0,
+                                              const int wm, const int wn, const int lg, const int li,
+                                              const unsigned ysplit) {
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  // Branch-free per element: every operand goes through a buffer descriptor clipped to THIS tile's valid rows, so
+  // ragged rows / columns are hardware range checks (loads return 0, stores are dropped) and all loads of one
+  // 16-column group are issued back to back before the math.  The variants (GEGLU | residual x per-image bias) are
+  // separate straight-line instantiations selected by uniform branches.
+  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
+  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
+  const bool do_silu = g.flags & MIMO_EPI_SILU;
+  const bool geglu = g.flags & MIMO_EPI_GEGLU;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const int n_out = geglu ? g.N / 2 : g.N;
+  const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.out + ((int64_t)ysplit * g.M + M0) * g.ldo * esz_o, 0,
+      (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
+      g.res ? (int)(((rows_valid - 1) * g.ldr + n_out) * esz_r) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
+  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
+  const int row0 = wm * 16 * MT + li;       // tile-local row of mi = 0
+  const int col0 = wn * 16 * NR + 4 * lg;   // tile-local column of ni = 0, r = 0
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+
+  auto epilogue = [&](auto has_res_c, auto has_imgb_c, auto geglu_c) {
+    constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
+    constexpr bool HAS_IMGB = decltype(has_imgb_c)::value != 0;
+    constexpr bool GEGLU = decltype(geglu_c)::value != 0;
+    // per-column-group constants: bias (for GEGLU bv[ni + 1] is the gate bias), column offsets, validity
+    f32x4 bv[NR];
+    bool col_ok[NR];
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const int n = N0 + col0 + ni * 16;
+      col_ok[ni] = n < g.N;
+      bv[ni] = ld4(r_bias, col_ok[ni] ? (unsigned)n * 4u : OOB);
+    }
+    // rows outer, column groups inner: consecutive stores of a lane fill one output row left to right
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const unsigned row = (unsigned)(row0 + mi * 16);
+      f32x4 ib[NR], rr[NR];
+      if (HAS_IMGB) {  // host guarantees M < 2^31 when a per-image bias is given
+        const unsigned img_off = ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+#pragma unroll
+        for (int ni = 0; ni < NR; ++ni)
+          ib[ni] = ld4(r_imgb, col_ok[ni] ? img_off + (unsigned)(N0 + col0 + ni * 16) * 4u : OOB);
+      }
+      if (HAS_RES) {
+        if (res_f32) {
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni)
+            rr[ni] = ld4(r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 4u : OOB);
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) {
+            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(
+                r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 2u : OOB, 0, 0);
+            rr[ni] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
+                             HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+          }
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NR; ni += (GEGLU ? 2 : 1)) {
+        if (GEGLU && ni + 1 >= NR) break;
+        f32x4 v = acc[ni][mi] + bv[ni];
+        if (HAS_IMGB) v += ib[ni];
+        if (GEGLU) {
+          // gate tile = the next 16 packed columns; identical lane mapping
+          const int ng = (ni + 1 < NR) ? ni + 1 : ni;
+          const f32x4 gt = acc[ng][mi] + bv[ng];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (g.flags & 0x100000u) ? gt[r] : gelu_erf_f(gt[r]);  // (ablation: no GELU)
+        }
+        if (do_silu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
+        if (HAS_RES) v += rr[ni];
+        v *= g.out_scale;
+        const int no = GEGLU ? (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg : N0 + col0 + ni * 16;  // output column
+        const unsigned ooff = col_ok[ni] ? (row * (unsigned)g.ldo + (unsigned)no) * esz_o : OOB;
+        if (out_f32) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+        } else {
+          u32x2 o;
+          o.x = pack2<DT>(v[0], v[1]);
+          o.y = pack2<DT>(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+        }
+      }
+    }
+  };
+  if (geglu) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
+  else if (g.res && g.img_bias) epilogue(IC<1>{}, IC<1>{}, IC<0>{});
+  else if (g.res) epilogue(IC<1>{}, IC<0>{}, IC<0>{});
+  else if (g.img_bias) epilogue(IC<0>{}, IC<1>{}, IC<0>{});
+  else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
+}
 
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
 template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE, int MT>
@@ -264,110 +376,134 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 
-  // ---- epilogue: lane holds out[m = .. + li][n = .. + 4*lg + r], r = 0..3 ----
-  // Branch-free per element: every operand goes through a buffer descriptor clipped to THIS tile's valid rows, so
-  // ragged rows / columns are hardware range checks (loads return 0, stores are dropped) and all loads of one
-  // 16-column group are issued back to back before the math.  The variants (GEGLU | residual x per-image bias) are
-  // separate straight-line instantiations selected by uniform branches.
-  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
-  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
-  const bool do_silu = g.flags & MIMO_EPI_SILU;
-  const bool geglu = g.flags & MIMO_EPI_GEGLU;
-  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
-  const int n_out = geglu ? g.N / 2 : g.N;
-  const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
-  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-      (char*)g.out + ((int64_t)blockIdx.y * g.M + M0) * g.ldo * esz_o, 0,
-      (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
-      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
-      g.res ? (int)(((rows_valid - 1) * g.ldr + n_out) * esz_r) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_bias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
-  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
-  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
-  const int row0 = wm * 16 * MT + li;       // tile-local row of mi = 0
-  const int col0 = wn * 16 * NR + 4 * lg;   // tile-local column of ni = 0, r = 0
-  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-  };
+  tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
+}
 
-  auto epilogue = [&](auto has_res_c, auto has_imgb_c, auto geglu_c) {
-    constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
-    constexpr bool HAS_IMGB = decltype(has_imgb_c)::value != 0;
-    constexpr bool GEGLU = decltype(geglu_c)::value != 0;
-    // per-column-group constants: bias (for GEGLU bv[ni + 1] is the gate bias), column offsets, validity
-    f32x4 bv[NR];
-    bool col_ok[NR];
+// Persistent dense GEMM (MODE 0, 2-deep ring): the grid is ONE resident set of blocks; block b walks tiles b, b + grid, ...
+// and its DMA cursor runs one K-tile ahead of its MFMA cursor ACROSS tile boundaries, so the first K-tile of the next
+// output tile lands under the last MFMAs and the epilogue of the current one (short-K linears: K = 320 is five K-tiles
+// per output tile and paid a full L2/HBM round trip plus a block launch per tile).  The loader keeps two VGPRs of state:
+// per-tile geometry lives in the (scalar) buffer descriptors, clipped to the tile's valid rows.
+template <int DT, int NR, int WM, int WN, int MT>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persist_kernel(const GemmArgs g) {
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NR * WN;
+  constexpr int PASS = THREADS / 8;
+  constexpr int NAJ = BM / PASS;
+  constexpr int NBJ = (BN + PASS - 1) / PASS;
+  constexpr int BNA = NBJ * PASS > BN ? BN + 8 : BN;
+  static_assert(BM % PASS == 0, "A tile must be a whole number of DMA passes");
+  constexpr int STAGE = (BM + BNA) * 8;
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lg = lane >> 4, li = lane & 15;
+  const int srow = tid >> 3;
+  const int sc = (tid & 7) ^ (srow & 7);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ntiles = g.ntiles;
+  const int nkt = g.nkt;
+
+  const unsigned a_thr = (unsigned)(((int64_t)srow * g.lda + sc * 8) * 2);  // byte offset inside the tile, pass 0
+  const unsigned b_thr = (unsigned)(((int64_t)srow * g.ldw + sc * 8) * 2);
+  const unsigned a_pass = (unsigned)(PASS * g.lda * 2), b_pass = (unsigned)(PASS * g.ldw * 2);
+  const bool b_tail_ok = srow + PASS * (NBJ - 1) < BN;  // rows of the last (partial) B pass that exist in the tile
+
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  auto dma = [&](const i32x4& r, unsigned off, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(r), "s"(lds_base) : "memory");
+  };
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+
+  // loader state: descriptors of the tile the DMA cursor is in (all scalar)
+  i32x4 rA, rW;
+  auto set_tile = [&](unsigned v) {
+    const bool valid = v < ntiles;
+    const unsigned L = valid ? xcd_remap(v, ntiles) : 0u;
+    const int64_t M0 = (int64_t)(L / (unsigned)g.tiles_n) * BM;
+    const int N0 = (int)(L % (unsigned)g.tiles_n) * BN;
+    const int64_t ra = valid ? ((g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM) : 0;
+    const int rb = valid ? ((g.N - N0) < BN ? (g.N - N0) : BN) : 0;
+    rA = make_rsrc(g.A + M0 * g.lda, ra > 0 ? (unsigned)(((ra - 1) * g.lda + g.K) * 2) : 0u);
+    rW = make_rsrc(g.W + (int64_t)N0 * g.ldw, rb > 0 ? (unsigned)(((int64_t)(rb - 1) * g.ldw + g.K) * 2) : 0u);
+  };
+  unsigned ld_v = blockIdx.x;
+  int ld_kt = 0;
+  set_tile(ld_v);
+  auto issue = [&](int slot) {
+    const unsigned kw = (unsigned)(ld_kt * BK * 2);
+    const bool cok = ld_kt * BK + sc * 8 < g.K;  // only the last K-tile of a ragged K can fail
+    const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int ni = 0; ni < NR; ++ni) {
-      const int n = N0 + col0 + ni * 16;
-      col_ok[ni] = n < g.N;
-      bv[ni] = ld4(r_bias, col_ok[ni] ? (unsigned)n * 4u : OOB);
+    for (int j = 0; j < NAJ; ++j)
+      dma(rA, cok ? a_thr + j * a_pass + kw : OOB, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const bool ok = cok && (j < NBJ - 1 || b_tail_ok);
+      const unsigned r0 = 8 * wave_u + PASS * j;
+      dma(rW, ok ? b_thr + j * b_pass + kw : OOB, slot_base + 16u * ((BM + (r0 < (unsigned)BN ? r0 : (unsigned)BN)) * 8));
     }
-    // rows outer, column groups inner: consecutive stores of a lane fill one output row left to right
+    if (++ld_kt == nkt) {
+      ld_kt = 0;
+      ld_v += gridDim.x;
+      set_tile(ld_v);
+    }
+  };
+  const bool late = (g.flags & 0x40000u) && ((wave_u >> 2) & 1);
+
+  issue(0);
+  int slot = 0;
+  for (unsigned cv = blockIdx.x; cv < ntiles; cv += gridDim.x) {
+    f32x4 acc[NR][MT];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const unsigned row = (unsigned)(row0 + mi * 16);
-      f32x4 ib[NR], rr[NR];
-      if (HAS_IMGB) {  // host guarantees M < 2^31 when a per-image bias is given
-        const unsigned img_off = ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+      // vmcnt(0): with a 2-deep ring every wait is a full drain anyway; it also retires the previous epilogue's stores
+      // (waiting at the END of the K-tile instead, so that the stores retire under the next tile's first MFMAs,
+      // measured 3-8 % slower)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const uint4* sa = &smem[slot * STAGE];
+      const uint4* sb = sa + BM * 8;
+      if (!late) issue(slot ^ 1);
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        if (sh == 1 && late) issue(slot ^ 1);
+        const int ch = (4 * sh + lg) ^ (li & 7);
+        uint4 fa[MT], fb[NR];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[mi] = sa[(wm * 16 * MT + mi * 16 + li) * 8 + ch];
+#pragma unroll
+        for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * 16 * NR + ni * 16 + li) * 8 + ch];
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni)
-          ib[ni] = ld4(r_imgb, col_ok[ni] ? img_off + (unsigned)(N0 + col0 + ni * 16) * 4u : OOB);
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
       }
-      if (HAS_RES) {
-        if (res_f32) {
-#pragma unroll
-          for (int ni = 0; ni < NR; ++ni)
-            rr[ni] = ld4(r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 4u : OOB);
-        } else {
-#pragma unroll
-          for (int ni = 0; ni < NR; ++ni) {
-            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(
-                r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 2u : OOB, 0, 0);
-            rr[ni] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
-                             HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
-          }
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NR; ni += (GEGLU ? 2 : 1)) {
-        if (GEGLU && ni + 1 >= NR) break;
-        f32x4 v = acc[ni][mi] + bv[ni];
-        if (HAS_IMGB) v += ib[ni];
-        if (GEGLU) {
-          // gate tile = the next 16 packed columns; identical lane mapping
-          const int ng = (ni + 1 < NR) ? ni + 1 : ni;
-          const f32x4 gt = acc[ng][mi] + bv[ng];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= (g.flags & 0x100000u) ? gt[r] : gelu_erf_f(gt[r]);  // (ablation: no GELU)
-        }
-        if (do_silu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-        }
-        if (HAS_RES) v += rr[ni];
-        v *= g.out_scale;
-        const int no = GEGLU ? (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg : N0 + col0 + ni * 16;  // output column
-        const unsigned ooff = col_ok[ni] ? (row * (unsigned)g.ldo + (unsigned)no) * esz_o : OOB;
-        if (out_f32) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
-        } else {
-          u32x2 o;
-          o.x = pack2<DT>(v[0], v[1]);
-          o.y = pack2<DT>(v[2], v[3]);
-          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
-        }
-      }
+      slot ^= 1;
     }
-  };
-  if (geglu) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
-  else if (g.res && g.img_bias) epilogue(IC<1>{}, IC<1>{}, IC<0>{});
-  else if (g.res) epilogue(IC<1>{}, IC<0>{}, IC<0>{});
-  else if (g.img_bias) epilogue(IC<0>{}, IC<1>{}, IC<0>{});
-  else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
+    const unsigned Lc = xcd_remap(cv, ntiles);
+    const int64_t M0 = (int64_t)(Lc / (unsigned)g.tiles_n) * BM;
+    const int N0 = (int)(Lc % (unsigned)g.tiles_n) * BN;
+    int lg_ = lg, li_ = li;
+    asm volatile("" : "+v"(lg_), "+v"(li_));  // keeps the epilogue's lane-invariant address math inside the tile loop
+    tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 }
 
 // Split-K reduction + the full epilogue: out = epi(sum_s partial[s]); one thread per 4 consecutive columns.
@@ -421,15 +557,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, in
 //   MIMO_GEMM_STAGGER=0     all waves issue their DMAs right after the barrier (default 1: staggered)
 //   MIMO_CONV_TAP_INNER=0   convolution K order tap-outer / channel-chunk-inner (default 1: tap inner)
 //   MIMO_GEMM_BM=256|192|128  force the XL8 tile height (default: picked per shape by wave quantisation)
+//   MIMO_GEMM_PERSIST=0     dense GEMMs launch one block per output tile (default 1: persistent blocks, cross-tile prefetch)
 //   MIMO_GEMM_SPLITK=0      never split K (default 1: long-K problems with too few tiles for the chip are split)
 //   MIMO_GEMM_ABLATE=1|2|3  timing experiments: skip DMA | skip MFMA | skip GELU (results are wrong)
 struct Tuning {
-  int cfg, ablate, stagger, tap_inner, splitk, bm;
+  int cfg, ablate, stagger, tap_inner, splitk, bm, persist;
 };
 Tuning read_tuning() {
   auto env = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
   return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1),
-                env("MIMO_GEMM_SPLITK", 1), env("MIMO_GEMM_BM", 0)};
+                env("MIMO_GEMM_SPLITK", 1), env("MIMO_GEMM_BM", 0), env("MIMO_GEMM_PERSIST", 1)};
 }
 Tuning& tuning() {
   static Tuning t = read_tuning();
@@ -506,6 +643,14 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     }
     const int64_t nwg = ((g.M + bm - 1) / bm) * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    // persistent blocks pay off (measured +2..7 %) for short reductions over many rounds of tiles — the level-0 linears;
+    // with 2-3 exactly filled rounds or long K the plain launch is faster (tools/microbench.py --ab MIMO_GEMM_PERSIST=0)
+    if (MODE == 0 && tn.persist && bm == 256 && nwg >= 3 * (int64_t)cus && g.nkt >= 2 && g.nkt <= 20) {
+      g.ntiles = (unsigned)nwg;
+      hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 2, 4, 8>), dim3((unsigned)cus), dim3(512), 0, st, g);
+      MIMO_LAUNCH_CHECK();
+      return MIMO_OK;
+    }
     if (bm == 256) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nwg), dim3(512), 0, st, g);
     else if (bm == 192) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 6>), dim3((unsigned)nwg), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 4>), dim3((unsigned)nwg), dim3(512), 0, st, g);
@@ -513,8 +658,14 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    if constexpr (NR == 4)
-      hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, 4>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+    if constexpr (NR == 4) {
+      if (MODE == 0 && tn.persist && nwg >= 3 * (int64_t)cus && g.nkt >= 2) {  // GEGLU: +6 % at every level
+        g.ntiles = (unsigned)nwg;
+        hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 4, 4, 4>), dim3((unsigned)cus), dim3(1024), 0, st, g);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, 4>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+      }
+    }
   } else if (cfg == 2) {
     g.tiles_n = tn_s;
     const int64_t nwg = m256 * tn_s;
