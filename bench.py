@@ -134,6 +134,19 @@ def measure_forward(pipe, dev, dtype, size, iters=3):
     return st.elapsed_time(en) / iters * 1e-3, flops, launches, fam
 
 
+def pmc_traffic(family):
+    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    over tools/profile_forward.py (same models, same shapes; PMC passes cannot run inside the timed region).
+    None when no summary has been committed for this build (tools/pmc_traffic.py writes it)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_forward_traffic.json")
+    try:
+        d = json.load(open(path))[family]
+        return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
+                "write": d["write_bytes_per_launch"], "source": "profiles/r1_pmc_forward_traffic.json"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(clip_flops, frames, budget_s=15.0):
     """Oracle (CPU fp32 PyTorch port of the reference path, oracle/models.py) timed on this host: one denoising-UNet
     forward of the FULL-SIZE model on a reduced sample (latent 16x16, 2 x 4 frames), FLOPs counted by torch's
@@ -271,7 +284,7 @@ def main():
             # its launches in one denoising forward / the sum of their HIP-event durations
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel", "achieved": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gk["flops"] / (gk["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS,
-                         "traffic": None, "launches_per_forward": gk["launches"], "avg_launch_us": gk["ms"] * 1e3 / gk["launches"],
+                         "traffic": pmc_traffic("gemm_kernel"), "launches_per_forward": gk["launches"], "avg_launch_us": gk["ms"] * 1e3 / gk["launches"],
                          "algorithmic_tflop_per_forward": gk["flops"] / 1e12,
                          "attn_kernel": {"achieved": fam["attn_kernel"]["flops"] / (fam["attn_kernel"]["ms"] * 1e-3) / 1e12,
                                          "launches_per_forward": fam["attn_kernel"]["launches"],
