@@ -8,7 +8,7 @@ Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, 
   forward512  FULL-SIZE denoising UNet, config-2 shapes: one forward on 2 x 24 latent frames 64x64 (about 4 min, 15 GB)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
   config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
-              0, 4, 9, 14, 19; about 50 min and 16 GB on 8 cores)
+              0, 9, 19; about 70 min and 19 GB on 8 cores)
 """
 import os
 import sys
@@ -97,10 +97,10 @@ def config1():
 
 def config2():
     """BASELINE configs[1] (the bench workload): 512x512, 24 frames (one context window), 20 DDIM steps, CFG 3.5."""
-    _clip(512, 24, 20, (0, 4, 9, 14, 19), "config2_512_24f_20steps.safetensors")
+    _clip(512, 24, 20, (0, 9, 19), "config2_512_24f_20steps.safetensors", keep_pose=False)
 
 
-def _clip(size, F, steps, keep, fname):
+def _clip(size, F, steps, keep, fname, keep_pose=True):
     from src.pipelines.pipeline_pose2vid_long_edit_bkfill_roiclip import Pose2VideoPipeline
     import src.models.pose_guider as pg
     r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, size // 8, 1234, 1235)
@@ -150,7 +150,8 @@ def _clip(size, F, steps, keep, fname):
                 traj[f"latents_step{i}"] = lat.clone()
             print("step", i, int(t), time.strftime("%H:%M:%S"), flush=True)
     traj["ref_latents"] = ref_lat
-    traj["pose_fea_frame0"] = pose_fea[:, :, 0].contiguous()
+    if keep_pose:
+        traj["pose_fea_frame0"] = pose_fea[:, :, 0].contiguous()
     save_file(traj, os.path.join(OUT, fname))
 
 

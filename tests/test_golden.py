@@ -138,8 +138,8 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
 @pytest.mark.gpu
 def test_hip_config2_pipeline_vs_reference_golden(full_models):
     """BASELINE configs[1] — the bench workload: 512x512, 24 frames, 20 DDIM steps, CFG 3.5, full-size models, VAE encode +
-    pose guider + reference UNet + 20 denoising forwards, against the reference's own code on CPU fp32 (about 50 min
-    there, oracle/make_golden.py config2).  Latents after steps 0, 4, 9, 14 and 19."""
+    pose guider + reference UNet + 20 denoising forwards, against the reference's own code on CPU fp32 (about 70 min
+    there, oracle/make_golden.py config2).  Latents after steps 0, 9 and 19 (the final latents)."""
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -161,11 +161,11 @@ def test_hip_config2_pipeline_vs_reference_golden(full_models):
     traj = []
     video = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 20, 3.5, trajectory=traj)
     assert video.shape == (1, 3, F, H, W) and bool(torch.isfinite(video).all())
-    keep = (0, 4, 9, 14, 19)
+    keep = (0, 9, 19)
     errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in keep]
-    line = "config-2 (512x512, 24 f, 20 steps) latents rel_l2 at steps 0/4/9/14/19: " + " ".join("%.2e" % e for e in errs)
+    line = "config-2 (512x512, 24 f, 20 steps) latents rel_l2 after steps 0/9/19: " + " ".join("%.2e" % e for e in errs)
     print(line)
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt"), "a") as f:
         f.write(line + "\n")
-    assert errs[0] < 1e-3 and max(errs) < 5e-3  # one forward: 1e-3; chained forwards accumulate operand rounding
+    assert max(errs) < 1e-3  # north_star bar: 1e-3 relative on the denoised latents of the headline configuration
