@@ -245,7 +245,7 @@ def main():
     for i in range(a.warmup):
         clip()
     barrier()
-    if rank == 0:
+    if rank == 0 or pipe.shard_windows:  # (the sharded clip contains collectives: every rank has to run it)
         pipe.stage_times = {}
         ops.COUNTER = {"flops": 0, "launches": 0}
         clip()  # one extra untimed clip: per-stage HIP-event marks + executed algorithmic FLOPs / launches

@@ -228,7 +228,10 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
       const bool need = (t == 0) | (mt > THR);
       if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
         float dlt = need ? ceilf(mt) : 0.f;
-        dlt = fminf(fmaxf(dlt, -2000.f - mq), 2000.f - mq);  // keeps |mq| an exactly representable integer
+        dlt = fminf(fmaxf(dlt, -2000.f - mq), 2000.f - mq);
+        // the reference actually used is the half-precision value stored in Q^T (fp16: every integer up to 2048;
+        // bf16: integers up to 256, coarser above) — move by the difference of the STORED values
+        dlt = HT<DT>::to_f(HT<DT>::from_f(mq + dlt)) - mq;
         if (t != 0) {
           const float alpha = fast_exp2(-dlt);
 #pragma unroll

@@ -293,8 +293,8 @@ def test_attention_forced_rescale(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("d,N,Nb,spike", [(40, 256, 256, False), (40, 130, 70, False), (40, 192, 0, True), (40, 200, 64, True),
-                                          (80, 100, 100, False), (160, 64, 0, True)])
+@pytest.mark.parametrize("d,N,Nb,spike", [(40, 256, 256, 0), (40, 130, 70, 0), (40, 192, 0, 4), (40, 200, 64, 4), (40, 192, 0, 40),
+                                          (80, 100, 100, 0), (160, 64, 0, 4)])
 def test_attention_prescaled_q(dev, dtype, d, N, Nb, spike):
     """q already carries softmax_scale * log2(e) (folded into W_q): C-ABI scale <= 0.  d = 40 runs the variant that
     keeps an integer reference max in a spare MFMA k-slot; the spike forces that reference to move in a late tile,
@@ -305,8 +305,8 @@ def test_attention_prescaled_q(dev, dtype, d, N, Nb, spike):
     g = 1.4426950408889634 * d ** -0.5
     qkv = rnd((B, N, 3 * C), dev, dtype, 11)
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    if spike:
-        k[1, N - 20] = (q[1, 7].float() * 4).to(dtype)   # late huge score for query 7 of batch 1
+    if spike:  # spike = 40: a logit of several hundred log2 units, beyond bf16's exactly representable integers
+        k[1, N - 20] = (q[1, 7].float() * spike).to(dtype)   # late huge score for query 7 of batch 1
         k[0, :64] = (-q[0, 5].float() * 2).to(dtype)     # whole first tile strongly negative for query 5 of batch 0
     qs = (q.float() * g).to(dtype)                        # what the GEMM with the folded W_q would have produced
     q_eff = qs.float() / g                                # the reference sees exactly the rounded operand
