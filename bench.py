@@ -270,7 +270,7 @@ def main():
         t_fwd, fwd_flops, fwd_launches, fam = measure_forward(pipe, dev, dtype, a.size)
         gk = fam["gemm_kernel"]
         out = {
-            "metric": "denoised frames/sec (512x512, 24f clip, 20 DDIM steps)", "value": total_frames / (elapsed / a.steps),
+            "metric": f"denoised frames/sec ({a.size}x{a.size}, {a.frames}f clip, {a.ddim_steps} DDIM steps)", "value": total_frames / (elapsed / a.steps),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {a.size}x{a.size}, {a.frames}-frame clip per GPU, {a.ddim_steps} DDIM steps, "
