@@ -182,3 +182,100 @@ def test_sharded_frames_world2_gloo():
     for p_ in procs:
         p_.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_pretrained_weights_layout_roundtrip(tmp_path):
+    """The reference's model construction sequence (run_animate.py:70-123) against a synthetic `pretrained_weights/` tree
+    (README.md:97-117) written from the oracle's reference-layout modules: every tensor must arrive where the reference
+    would put it — SD1.5 2-D weights inflated into the 3-D UNet (conv_in zero-padded 4 -> 8 channels), motion module file,
+    the three fine-tuned .pth files, the VAE with the deprecated attention key names, the CLIP image encoder."""
+    import json
+    from safetensors.torch import save_file
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    from mimo_amd.scheduler import DDIMScheduler
+    from mimo_amd.unet import UNet2DConditionModel, UNet3DConditionModel
+    from mimo_amd.vae import AutoencoderKL, PoseGuider
+    from oracle import models as OM, primitives as OP, synth
+    kw = synth.small_unet_kwargs()
+    o2 = synth.build(OM.UNet2DConditionModel, 41, **kw)
+    o3 = synth.build(OM.UNet3DConditionModel, 42, motion_heads=4, **kw)
+    opg = synth.build(OM.PoseGuider, 43)
+    ovae = synth.build(OP.AutoencoderKL, 44, block_out_channels=(32, 64, 64, 64), norm_num_groups=8)
+    ccfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                            image_size=28, patch_size=14, projection_dim=64)
+    oclip = RefCLIP(ccfg).eval()
+
+    root = tmp_path / "pretrained_weights"
+    unet_dir = root / "stable-diffusion-v1-5" / "unet"
+    unet_dir.mkdir(parents=True)
+    (unet_dir / "config.json").write_text(json.dumps(dict(
+        _class_name="UNet2DConditionModel", sample_size=64, in_channels=4, out_channels=4, layers_per_block=2,
+        block_out_channels=list(kw["block_out_channels"]), norm_num_groups=kw["norm_num_groups"], norm_eps=1e-5,
+        cross_attention_dim=768, attention_head_dim=kw["attention_head_dim"], act_fn="silu",
+        down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"])))
+    sd15 = {k: v.clone() for k, v in o2.state_dict().items()}
+    sd15["conv_norm_out.weight"] = torch.ones(kw["block_out_channels"][0])   # the stock SD1.5 file has an output head
+    sd15["conv_norm_out.bias"] = torch.zeros(kw["block_out_channels"][0])
+    sd15["conv_out.weight"] = torch.zeros(4, kw["block_out_channels"][0], 3, 3)
+    sd15["conv_out.bias"] = torch.zeros(4)
+    torch.save(sd15, unet_dir / "diffusion_pytorch_model.bin")
+    sd3 = o3.state_dict()
+    torch.save({k: v for k, v in sd3.items() if "motion_modules." in k}, root / "motion_module.pth")
+    torch.save(sd3, root / "denoising_unet.pth")
+    torch.save(o2.state_dict(), root / "reference_unet.pth")
+    torch.save(opg.state_dict(), root / "pose_guider.pth")
+    vae_dir = root / "sd-vae-ft-mse"
+    vae_dir.mkdir()
+    (vae_dir / "config.json").write_text(json.dumps(dict(
+        _class_name="AutoencoderKL", in_channels=3, out_channels=3, block_out_channels=[32, 64, 64, 64], layers_per_block=2,
+        latent_channels=4, norm_num_groups=8, act_fn="silu", sample_size=256, scaling_factor=0.18215,
+        down_block_types=["DownEncoderBlock2D"] * 4, up_block_types=["UpDecoderBlock2D"] * 4)))
+    dep = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    vsd = {}
+    for k, v in ovae.state_dict().items():
+        if ".attentions." in k:
+            for new, old in dep.items():
+                k = k.replace("." + new + ".", "." + old + ".")
+        vsd[k] = v.contiguous()
+    assert any(".query." in k for k in vsd)
+    save_file(vsd, str(vae_dir / "diffusion_pytorch_model.safetensors"))
+    enc_dir = root / "image_encoder"
+    enc_dir.mkdir()
+    (enc_dir / "config.json").write_text(json.dumps(ccfg.to_dict(), default=str))
+    torch.save(oclip.state_dict(), enc_dir / "pytorch_model.bin")
+
+    # ---- the reference's sequence, with the imports swapped (INTEGRATION.md section 1) ----
+    vae = AutoencoderKL.from_pretrained(str(vae_dir))
+    reference_unet = UNet2DConditionModel.from_pretrained(str(root / "stable-diffusion-v1-5"), subfolder="unet")
+    unet_additional_kwargs = dict(
+        use_inflated_groupnorm=True, unet_use_cross_frame_attention=False, unet_use_temporal_attention=False,
+        use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=True,
+        motion_module_decoder_only=False, motion_module_type="Vanilla",
+        motion_module_kwargs=dict(num_attention_heads=4, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+                                  temporal_position_encoding=True, temporal_position_encoding_max_len=32, temporal_attention_dim_div=1))
+    denoising_unet = UNet3DConditionModel.from_pretrained_2d(str(root / "stable-diffusion-v1-5"), str(root / "motion_module.pth"),
+                                                             subfolder="unet", unet_additional_kwargs=unet_additional_kwargs)
+    # 2-D -> 3-D inflation: latent half of conv_in = the 2-D weights, background half = zeros; motion modules from the file
+    w_in = denoising_unet.state_dict()["conv_in.weight"]
+    assert torch.equal(w_in[:, :4], o2.state_dict()["conv_in.weight"]) and float(w_in[:, 4:].abs().max()) == 0.0
+    k_mm = next(k for k in sd3 if "motion_modules." in k and k.endswith("to_q.weight"))
+    assert torch.equal(denoising_unet.state_dict()[k_mm], sd3[k_mm])
+    k_sp = next(k for k in sd3 if "attentions." in k and k.endswith("attn1.to_q.weight"))
+    assert torch.equal(denoising_unet.state_dict()[k_sp], o2.state_dict()[k_sp])
+    pose_guider = PoseGuider(320, conditioning_channels=3, block_out_channels=(16, 32, 96, 256))
+    image_enc = CLIPVisionModelWithProjection.from_pretrained(str(enc_dir))
+    DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
+    missing, unexpected = denoising_unet.load_state_dict(torch.load(root / "denoising_unet.pth", map_location="cpu"), strict=False)
+    assert not missing and not unexpected
+    reference_unet.load_state_dict(torch.load(root / "reference_unet.pth", map_location="cpu"))   # strict, as the reference
+    pose_guider.load_state_dict(torch.load(root / "pose_guider.pth", map_location="cpu"))
+
+    def same(prod, ref_sd, rename=None):
+        psd = prod.state_dict()
+        assert set(psd) == {k for k in ref_sd if not k.endswith("position_ids")}
+        return all(torch.equal(psd[k], ref_sd[k]) for k in psd)
+
+    assert same(denoising_unet, sd3) and same(reference_unet, o2.state_dict()) and same(pose_guider, opg.state_dict())
+    assert same(vae, ovae.state_dict()) and same(image_enc, oclip.state_dict())
