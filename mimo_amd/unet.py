@@ -8,7 +8,6 @@
 State-dict keys are those of the reference classes (1274 / 682 entries at SD1.5 size).
 """
 import json
-import os
 from pathlib import Path
 
 import torch
