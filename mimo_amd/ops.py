@@ -196,13 +196,13 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
         if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
             # row-streaming statistics: one block per (image, pixel slice) reads whole pixel rows; the slices'
             # (S, Q) partials are reduced in fixed order (deterministic)
-            split = max(1, min(-(-2048 // n), HW // 16))
+            # (the slicing is a function of the image size only: a frame's statistics must not depend on how many
+            # other frames share the launch, or the sharded long-clip mode would not reproduce the single-GPU bits)
+            split = max(1, min(256, HW // 96))
             partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32)
         else:
-            # one block per (image, group); few pairs over a lot of pixels: slice the pixels to fill the chip
-            split = 1
-            if n * groups < 1024:
-                split = max(1, min(2048 // (n * groups), HW // 1024))
+            # one block per (image, group), pixel-sliced for large images
+            split = max(1, min(8, HW // 4096))
             partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
         L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
                float(eps), stats.data_ptr(), _ptr(partials), split, _stream())

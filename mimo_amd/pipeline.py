@@ -47,6 +47,20 @@ def plan_units(num_windows, cfg, rank, world):
     return units, [u for i, u in enumerate(units) if i % world == rank]
 
 
+def _all_gather(send, world, group=None):
+    """all_gather of equal-shape tensors.  RCCL (backend "nccl") takes device tensors as they are; the gloo backend
+    (CPU tests, and the 2-ranks-on-one-GPU test) has no device all_gather, so device tensors are staged through the host."""
+    import torch.distributed as dist
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host = send.cpu()
+        recv = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(recv, host, group=group)
+        return [r.to(send.device) for r in recv]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send.contiguous(), group=group)
+    return recv
+
+
 def sharded_frames(fn, x, rank, world, group=None):
     """Per-frame stage (VAE encode / decode, pose guider) over frames [F, ...] with the frames dealt in contiguous
     chunks over the ranks: every rank runs `fn` on its chunk only, one all_gather rebuilds the full result on every
@@ -60,9 +74,7 @@ def sharded_frames(fn, x, rank, world, group=None):
     send = torch.zeros((per,) + tuple(mine.shape[1:]), device=mine.device, dtype=mine.dtype)
     if hi > lo:
         send[:hi - lo] = mine
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    return torch.cat(recv, 0)[:F].contiguous()
+    return torch.cat(_all_gather(send, world, group), 0)[:F].contiguous()
 
 
 def exchange_predictions(my_preds, units, rank, world, group=None):
@@ -75,8 +87,7 @@ def exchange_predictions(my_preds, units, rank, world, group=None):
         raise RuntimeError("every rank must own at least one unit (world size > number of units)")
     mine = [u for i, u in enumerate(units) if i % world == rank]
     send = torch.stack([my_preds[u] for u in mine] + [torch.zeros_like(proto)] * (per_rank - len(mine)))
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send.contiguous(), group=group)
+    recv = _all_gather(send, world, group)
     out = {}
     for i, u in enumerate(units):
         out[u] = recv[i % world][i // world]

@@ -255,3 +255,55 @@ def test_clip_image_encoder_vs_transformers(dev, dtype, size):
     e2 = rel_l2(o.last_hidden_state.float().cpu(), r.last_hidden_state)
     report(f"clip image encoder {size} {dtype}: image_embeds rel_l2={e1:.2e} last_hidden rel_l2={e2:.2e}")
     assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
+
+
+def _sharded_clip_worker(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        q.put((rank, _small_clip(torch.device("cuda:0"), shard=True).cpu().numpy()))  # by value: the worker exits
+    finally:
+        dist.destroy_process_group()
+
+
+def _small_clip(dev, shard=False, invariant=False):
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    dtype = torch.float16
+    _, _, p3, p2 = build_pair_unets(dtype, dev, seed=61)
+    _, pv = build_pair_vae(dtype, dev, seed=62)
+    _, pg = build_pair_pose(dtype, dev, seed=63)
+    H = W = 64
+    F = 26  # two wrapped 24-frame windows -> 4 (window, CFG-half) units
+    g = torch.Generator().manual_seed(7)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    pipe.shard_windows, pipe.batch_invariant = shard, invariant
+    vid, latents = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, 3.5, return_latents=True)
+    return torch.cat([latents.flatten(), vid.flatten()])
+
+
+def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev):
+    """one clip whose (window, CFG-half) units and per-frame stages are dealt over 2 ranks (both on this
+    GPU, collectives over gloo with host staging — RCCL refuses two ranks on one device) must reproduce the single-process
+    result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides)."""
+    import torch.multiprocessing as mp
+    import os
+    single = _small_clip(dev, invariant=True).cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400 + 11
+    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = {r: torch.from_numpy(v) for r, v in (q.get(timeout=600) for _ in procs)}
+    for p_ in procs:
+        p_.join(timeout=120)
+    assert torch.isfinite(single).all()
+    assert torch.equal(res[0], single) and torch.equal(res[1], single)
+    report("sharded long clip (2 ranks, F = 26, 2 steps, fp16): latents and video bit-identical to the single-process run")
