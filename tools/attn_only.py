@@ -12,9 +12,25 @@ n, N, C = 48, 4096, 320
 qkv = torch.randn(n, N, 3 * C, device=dev).half()
 bank = torch.randn(N, 2 * C, device=dev).half()
 q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+def run():
+    return ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=24, q_prescaled="--slow" not in sys.argv)
+
+
 for _ in range(3):
-    ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=24, q_prescaled="--slow" not in sys.argv)
+    run()
 torch.cuda.synchronize()
+if "--time" in sys.argv:  # A/B of an environment knob read per launch: python tools/attn_only.py --time MIMO_ATTN_KT32
+    knob = sys.argv[sys.argv.index("--time") + 1]
+    for env in ("0", "1", "0", "1"):
+        os.environ[knob] = env
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run()
+        st.record()
+        for _ in range(10):
+            o = run()
+        en.record()
+        torch.cuda.synchronize()
+        print(f"{knob}={env}: {st.elapsed_time(en)/10:.3f} ms  checksum {float(o.float().abs().mean()):.6f}", flush=True)
 import threading
 t = threading.Timer(30.0, os._exit, [0])
 t.daemon = True
