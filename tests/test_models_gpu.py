@@ -307,3 +307,55 @@ def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev):
     assert torch.isfinite(single).all()
     assert torch.equal(res[0], single) and torch.equal(res[1], single)
     report("sharded long clip (2 ranks, F = 26, 2 steps, fp16): latents and video bit-identical to the single-process run")
+
+
+def test_pipeline_call_surface_pil_inputs(dev):
+    """The reference's call surface (run_animate.py:208-218 / run_edit.py): PIL reference image, lists of PIL pose and
+    per-frame background images (config 3: non-constant backgrounds), CPU generator, `.videos` [1,3,F,H,W] float32 on the
+    host in [0,1] — with the HIP CLIP encoder as `image_encoder` — against the oracle's tensor-level clip."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    dtype = torch.float16
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=71)
+    ov, pv = build_pair_vae(dtype, dev, seed=72)
+    og, pg = build_pair_pose(dtype, dev, seed=73)
+    ccfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                            image_size=224, patch_size=32, projection_dim=768)
+    torch.manual_seed(5)
+    oclip = RefCLIP(ccfg).eval()
+    pclip = CLIPVisionModelWithProjection(ccfg)
+    pclip.load_state_dict({k: v for k, v in oclip.state_dict().items() if not k.endswith("position_ids")})
+    pclip.to(dev)
+    pclip.compute_dtype = dtype
+    H = W = 64
+    F = 8
+    ref_img = Image.fromarray(np.random.RandomState(0).randint(0, 256, (H, W, 3), dtype=np.uint8))
+    poses = [Image.fromarray(np.random.RandomState(100 + i).randint(0, 256, (H, W, 3), dtype=np.uint8)) for i in range(F)]
+    bks = [Image.fromarray(np.random.RandomState(200 + i).randint(0, 256, (H, W, 3), dtype=np.uint8)) for i in range(F)]
+    pipe = Pose2VideoPipeline(vae=pv, image_encoder=pclip, reference_unet=p2, denoising_unet=p3, pose_guider=pg,
+                              scheduler=DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    seen = []
+    out = pipe(ref_img, poses, bks, W, H, F, 2, 3.5, generator=torch.manual_seed(42),
+               callback=lambda i, t, lat: seen.append(int(t)), callback_steps=1).videos
+    assert out.shape == (1, 3, F, H, W) and out.dtype == torch.float32 and out.device.type == "cpu"
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and len(seen) == 2
+    # oracle: same preprocessing on tensors, transformers CLIP on CPU for the embedding, same injected latents
+    from transformers import CLIPImageProcessor
+    to_t = lambda im: torch.from_numpy(np.array(im).astype(np.float32) / 255.0).permute(2, 0, 1)
+    px = CLIPImageProcessor().preprocess(ref_img.resize((224, 224)), return_tensors="pt").pixel_values
+    with torch.no_grad():
+        emb = oclip(pixel_values=px).image_embeds
+        lat = torch.randn((1, 4, F, H // 8, W // 8), generator=torch.manual_seed(42))
+        vid_o, _ = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), emb,
+                            (2 * to_t(ref_img) - 1)[None], torch.stack([2 * to_t(b) - 1 for b in bks]),
+                            torch.stack([to_t(p) for p in poses]), lat, 2, 3.5)
+    e = rel_l2(out, vid_o)
+    report(f"pipeline __call__ (PIL inputs, HIP CLIP, per-frame backgrounds) fp16: video rel_l2={e:.2e}")
+    assert e < 3e-3
