@@ -7,15 +7,17 @@
 //
 // Reference ops replaced: see include/mimo_hip.h (mimo_gemm / mimo_conv2d).
 //
-// Tiling (gfx950): block = 2*WM waves laid out WM x 2; block tile (64*WM) x (32*NR) x 64;
-// each wave owns 64 x (16*NR) as 4 x NR MFMA 16x16x32 tiles, fp32 accumulators in VGPRs.
+// Tiling (gfx950): block = WM x WN waves; block tile (16*MT*WM) x (16*NR*WN) x 64; each wave owns
+// (16*MT) x (16*NR) as MT x NR MFMA 16x16x32 tiles, fp32 accumulators in VGPRs.
 // Operands go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`): hardware range checking
 // turns padding taps / ragged edges into zero fill, the XOR swizzle that makes the
 // ds_read_b128 fragment reads bank-conflict-free is applied on the SOURCE address (the DMA
 // writes lane-linear), and an NSTAGE-deep LDS ring keeps NSTAGE-1 K-tiles in flight under
-// the MFMAs with ONE barrier and one counted `s_waitcnt vmcnt` per K-tile.
-//   WM = 2, NSTAGE = 2 (128-row tile, 72-80 KB LDS, 2 blocks/CU): small / skinny problems
-//   WM = 4, NSTAGE = 3 (256-row tile, 144-159 KB LDS, 1 block/CU): large-M problems
+// the MFMAs with ONE barrier and one counted `s_waitcnt vmcnt` per K-tile.  Configurations
+// (picked per shape in launch_nr): S 2x2 waves, 128-row tile, 2 blocks/CU; L 4x2, 3-deep ring;
+// XL 4x4 = 16 waves 256 x 256 (GEGLU); XL8 2x4 = 8 waves with a 256-register budget,
+// (256|192|128) x 320; split-K over gridDim.y for long reductions over few tiles;
+// gemm_dense_persist_kernel = the dense case as persistent blocks with cross-tile prefetch.
 // The MFMA is issued "swapped" (W fragment as the A operand) so that every lane ends up
 // with 4 consecutive output columns of one row -> 16-byte epilogue loads/stores.
 #include <stdlib.h>
