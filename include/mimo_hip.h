@@ -11,7 +11,8 @@
  * Conventions
  *   - plain pointers + sizes; no torch types.  All pointers are DEVICE pointers that
  *     the caller allocated (torch.empty(...).data_ptr()); the library never allocates,
- *     frees or retains device memory and keeps no mutable global state.
+ *     frees or retains device memory, reads no environment variable and keeps no mutable
+ *     global state (every launch is a pure function of its arguments).
  *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*).
  *   - return 0 on success; negative MIMO_E* for a rejected argument; positive values
  *     are hipError_t from the launch.
@@ -42,6 +43,8 @@ extern "C" {
 #define MIMO_EPI_GEGLU 2u     /* weight rows interleaved [16 value | 16 gate]; out = value*gelu_erf(gate), N_out = N/2 */
 #define MIMO_EPI_OUT_F32 4u   /* store fp32 (else half16) */
 #define MIMO_EPI_RES_F32 8u   /* residual tensor is fp32 (else half16) */
+#define MIMO_EPI_NO_SPLITK 16u /* never split the K reduction of THIS call (its fp32 summation order then does not
+                                  depend on the row count M, i.e. on how a clip is cut into batches) */
 
 int mimo_version(void);
 
@@ -52,8 +55,9 @@ int mimo_version(void);
  * M * N <= 2^22 output elements (the SD1.5 8x8 level at 48 images); the library never allocates device memory. */
 size_t mimo_workspace_bytes(void);
 
-/* Re-read the MIMO_GEMM_* / MIMO_CONV_* tuning environment variables (they are otherwise read once, at the first
- * launch).  Not a reference interface: used by tools/microbench.py for interleaved A/B timing.  Returns 0. */
+/* No-op kept for tools/microbench.py.  The shipped library reads no environment variable and has no mutable global
+ * state: every tuning knob is a compile-time constant.  (The separate -DMIMO_TUNE build of the same sources,
+ * libmimo_hip_tune.so, reads MIMO_* knobs from the environment at every launch for interleaved A/B timing.)  Returns 0. */
 int mimo_reload_tuning(void);
 
 /* ---------------------------------------------------------------------------------
@@ -77,6 +81,37 @@ int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, i
               int64_t M, int N, int K, const float* bias, const float* img_bias,
               int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
               float out_scale, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused side outputs of the GEMM / convolution epilogue (mimo_gemm_ext / mimo_conv2d_ext; ext == NULL is the
+ * plain call).  They remove whole HBM passes of the normalisation layers that FOLLOW the producing op:
+ *   colstats  fp32 [M/32][2][N] (M % 32 == 0): for every 32-row slab and column, the mean and the sum of squared
+ *             deviations from that mean of the values this call stores.  mimo_group_norm_stats_cols() merges them
+ *             into GroupNorm (mean, rstd) — the statistics pass of InflatedGroupNorm / nn.GroupNorm
+ *             (src/models/resnet.py:20-28, transformer_3d.py:124, motion_module.py:154) never re-reads the tensor.
+ *             A call with colstats never splits K.
+ *   ln_out    half16 [M, N]: LayerNorm(out row) * ln_gamma + ln_beta (+ ln_pe[(m / ln_rows_per_frame) % ln_pe_frames])
+ *             of every output row, eps ln_eps — the nn.LayerNorm (+ PositionalEncoding) that consumes this GEMM's
+ *             result (src/models/attention.py:329-360,391-429; src/models/motion_module.py:230-258,276-279).
+ *             mimo_gemm_ext only; needs N == 320 (one tile holds whole rows), ldo == N, no SILU/GEGLU, and with
+ *             ln_pe: ln_rows_per_frame % 128 == 0.  Other shapes: call mimo_layer_norm.
+ * --------------------------------------------------------------------------------- */
+typedef struct mimo_epilogue_ext {
+  float* colstats;
+  void* ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_pe;
+  float ln_eps;
+  int ln_pe_frames;
+  int64_t ln_rows_per_frame;
+} mimo_epilogue_ext;
+
+int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+                  int64_t M, int N, int K, const float* bias, const float* img_bias,
+                  int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
+                  float out_scale, unsigned flags, void* workspace, size_t workspace_bytes,
+                  const mimo_epilogue_ext* ext, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * mimo_conv2d: channels-last implicit-GEMM convolution (3x3 or 1x1), MFMA.
@@ -113,6 +148,11 @@ int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void*
                 const mimo_conv_params* p, const float* bias, const float* img_bias,
                 const void* residual, float out_scale, unsigned flags, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* as mimo_conv2d, plus ext->colstats (ext->ln_out must be NULL) */
+int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const void* W, void* out,
+                    const mimo_conv_params* p, const float* bias, const float* img_bias,
+                    const void* residual, float out_scale, unsigned flags, void* workspace,
+                    size_t workspace_bytes, const mimo_epilogue_ext* ext, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * GroupNorm (per image, 32 groups typical) over a *virtual channel concat* of two
@@ -128,6 +168,12 @@ int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void*
 int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, float eps, float* stats, float* partials,
                           int split, void* stream);
+/* GroupNorm statistics from epilogue column statistics (mimo_epilogue_ext.colstats) of the one or two tensors of the
+ * virtual concat: cs1 fp32 [n*HW/32][2][C1], cs2 [n*HW/32][2][C2] (nullable, C2 = 0); HW % 32 == 0.  One wave per
+ * (image, group) merges slabs x columns with Chan's parallel variance update in double, fixed order.
+ * stats: fp32 [n, groups, 2] = (mean, rstd), exactly what mimo_group_norm_apply consumes. */
+int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
+                               int groups, float eps, float* stats, void* stream);
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);

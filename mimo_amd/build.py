@@ -25,9 +25,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    objdir = os.path.join(ROOT, "_obj")
+TUNE_LIB_PATH = os.path.join(ROOT, "libmimo_hip_tune.so")
+
+
+def build(force: bool = False, verbose: bool = False, tune: bool = False) -> str:
+    """tune=False: the shipped library (no environment reads, no mutable state).  tune=True: the same sources with
+    -DMIMO_TUNE -> libmimo_hip_tune.so, whose MIMO_* knobs tools/microbench.py flips for interleaved A/B timing
+    (load it with MIMO_HIP_LIB=.../libmimo_hip_tune.so)."""
+    objdir = os.path.join(ROOT, "_obj_tune" if tune else "_obj")
     os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + (["-DMIMO_TUNE"] if tune else [])
+    lib_path = TUNE_LIB_PATH if tune else LIB_PATH
     headers = [os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "mimo_hip.h")]
     jobs = []
     objs = []
@@ -36,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -48,10 +56,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB_PATH, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+    if jobs or force or _stale(lib_path, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tune="--tune" in sys.argv))

@@ -21,6 +21,10 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KV_TILE = 64;
 constexpr float LOG2E = 1.4426950408889634f;
+template <int V>
+struct IC2 {
+  static constexpr int value = V;
+};
 
 // raw v_exp_f32: arguments are <= 0 here, results below 2^-126 may flush to zero (libm exp2f adds a
 // denormal-range rescale = 4 extra VALU ops per element, which matters in the softmax inner loop)
@@ -348,6 +352,386 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 }
 
 // ------------------------------------------------------------------------------------
+// attn40_kernel: the d = 40 level (N = 4096 at 512x512: the largest single kernel of the denoising forward),
+// Q pre-multiplied by softmax_scale * log2(e).  Differences from attn_kernel, each aimed at a measured limit of it
+// (profiles/r1_pmc_sq_counters_attn_and_conv.txt: MFMA pipe 48 % busy, 11 VALU-class instructions per MFMA):
+//   * a wave owns 64 queries (two 32-query blocks A, B), a block 256: every K / V^T fragment read from LDS feeds
+//     twice the MFMAs, and the K/V stream per FLOP (L2 -> LDS) is half that of a 128-query block;
+//   * P.V runs on 16x16x32 MFMAs: O^T is 48 rows (40 + the ones-row that yields the softmax denominators), not 64.
+//     The 32x32 S^T accumulators become 16x16x32 B operands with one v_permlane16_swap per packed register pair
+//     (odd 16-lane rows of one register <-> even rows of the other), no LDS round trip;
+//   * the softmax costs exp + pack only: the integer reference max rides in the spare QK^T k-slot (as in
+//     attn_kernel<40, FAST>), and instead of a running max the packed P words are OR-ed together — bit 14 of a half
+//     is set exactly when p >= 2, i.e. a score overshot the reference (which is kept 3 above the running max).
+//     Only then (and on the first tile) S is recomputed and re-referenced: exact softmax arithmetic either way;
+//   * program order per KV tile: QK^T(A) | QK^T(B) with softmax(A) in its shadow | P.V(A) with softmax(B) in its
+//     shadow | P.V(B) with the next tile's V^T staging in its shadow;
+//   * K tiles go global -> LDS by DMA (row pitch 80 B is bank-conflict-free for the fragment reads as it is), the
+//     bias column of the reference-max trick is a constant 16-byte LDS slot; V^T is staged as packed kv pairs
+//     (8 ds_write_b32 per thread instead of 16 ds_write_b16) in a kv order that makes a fragment ONE ds_read_b128;
+//   * 1-D grid, XCD-aware: consecutive logical blocks (same batch row and head = same K/V) run on one XCD and hit in
+//     its L2; cond (two KV segments) and uncond batch rows alternate so every XCD gets the same work.
+// ------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT, int ORDER>
+__global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
+  constexpr int D = 40;
+  constexpr int KROWB = 80;                 // K tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
+  constexpr int KBUF = KV_TILE * KROWB;     // 5120 B per K buffer
+  constexpr int VROWB = 160;                // V^T row pitch in bytes: 64 kv halfs + pad (conflict-free ds_read_b128)
+  constexpr int VROWS = 48;                 // d rows: 40 + row 40 = ones (denominator) + 7 zero rows
+  constexpr int VBUF = VROWS * VROWB;       // 7680 B per V^T buffer
+  constexpr int CONST_OFF = 2 * KBUF;       // 16-byte slot (1, 0, ..., 0): K columns 40..47 of every row
+  constexpr int V_OFF = CONST_OFF + 64;
+  constexpr int DUMMY_OFF = V_OFF + 2 * VBUF;  // write-only scratch: threads without a staging item store here (branch-free)
+  constexpr float HEAD = 3.f;               // the reference sits HEAD above the running max: p <= 2^-3 until it is overshot
+  // ONE LDS object (a second one would make hipcc drain vmcnt before every fragment read)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DUMMY_OFF + 7 * VROWB + 256];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h2 = lane >> 5, li = lane & 31;   // 32x32 MFMA view: query column li, row half h2
+  const int g = lane >> 4, i16 = lane & 15;   // 16x16 MFMA view: k-slot group g, row / column i16
+
+  // ---- block -> (batch row, head, 256-query block); logical id L walks query blocks fastest ----
+  const unsigned nqb = (unsigned)((a.Nq + 255) / 256);
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned qblk = L % nqb;
+  const unsigned hb = L / nqb;
+  const int head = (int)(hb % (unsigned)a.heads);
+  int b = (int)(hb / (unsigned)a.heads);
+  if (a.k2 && a.Nk2 > 0 && 2 * a.seg2_first_batch == a.B)  // alternate long (two-segment) and short batch rows
+    b = (b & 1) ? (b >> 1) : a.seg2_first_batch + (b >> 1);
+  const int q0 = (int)qblk * 256 + wave * 64;
+
+  // ---- LDS init: V^T buffers zero, row 40 ones; the constant K slot ----
+  for (int i = tid; i < 2 * VBUF / 4; i += 256) reinterpret_cast<uint32_t*>(smem + V_OFF)[i] = 0u;
+  if (tid < 4) reinterpret_cast<uint32_t*>(smem + CONST_OFF)[tid] = tid == 0 ? (uint32_t)HT<DT>::from_f(1.0f) : 0u;
+  __syncthreads();
+  {
+    const uint32_t one2 = (uint32_t)HT<DT>::from_f(1.0f) * 0x10001u;
+    for (int i = tid; i < 2 * (VROWB / 4); i += 256)
+      reinterpret_cast<uint32_t*>(smem + V_OFF + (i / (VROWB / 4)) * VBUF + D * VROWB)[i % (VROWB / 4)] = one2;
+  }
+
+  // ---- Q^T fragments (B operand of the 32x32x16 MFMA): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8] ----
+  uint4 qf[2][3];
+  {
+    const uint16_t* qb = a.q + (int64_t)b * a.Nq * a.ldq;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)((int64_t)a.Nq * a.ldq * 2), 0x00020000);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int qr = q0 + 32 * x + li;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int kk = 16 * s + 8 * h2;
+        const bool ok = (qr < a.Nq) & (kk < D);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)(((int64_t)qr * a.ldq + head * D + kk) * 2) : 0xFFFFFFF0u, 0, 0);
+        qf[x][s] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+
+  // O^T accumulators, 16x16 tiles: ot[x][dt][j]: lane (g, n) holds O^T[d = 16 dt + 4 g + r][q = 32 x + 16 j + n]
+  f32x4 ot[2][3][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 3; ++y)
+#pragma unroll
+      for (int z = 0; z < 2; ++z) ot[x][y][z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mq[2] = {0.f, 0.f};  // integer reference folded into Q^T row 40 of each query block
+
+  const bool has2 = a.k2 && a.Nk2 > 0 && b >= a.seg2_first_batch;
+  const int T0 = (a.Nk + KV_TILE - 1) / KV_TILE;
+  const int T = T0 + (has2 ? (a.Nk2 + KV_TILE - 1) / KV_TILE : 0);
+  const uint16_t* kb0 = a.k + (int64_t)b * a.Nk * a.ldk;
+  const uint16_t* vb0 = a.v + (int64_t)b * a.Nk * a.ldv;
+
+  // ---- K tile DMA: 320 16-byte chunks = 5 wave-DMAs; wave w issues DMA w, wave 0 also DMA 4 ----
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t p64 = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)p64; r.y = (int)((uint32_t)(p64 >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0];
+  int krow_[2];
+  unsigned kcol_[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int c = 64 * (jj == 0 ? wave : 4) + lane;
+    krow_[jj] = c / 5;
+    kcol_[jj] = (unsigned)((head * D + (c - krow_[jj] * 5) * 8) * 2);
+  }
+  auto dma_k = [&](int t, int buf) {
+    const bool s2 = t >= T0;
+    const uint16_t* kb = s2 ? a.k2 : kb0;
+    const unsigned ldkb = (unsigned)((s2 ? a.ldk2 : a.ldk) * 2);
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const i32x4 rk = make_rsrc(kb, (unsigned)((int64_t)nk * ldkb));
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      if (jj == 1 && wave != 0) break;  // wave-uniform
+      const bool ok = kv0 + krow_[jj] < nk;
+      const unsigned off = ok ? (unsigned)(kv0 + krow_[jj]) * ldkb + kcol_[jj] : 0xFFFFFFF0u;
+      const unsigned dst = smem_base + (unsigned)(buf * KBUF + 1024 * (jj == 0 ? wave : 4));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off), "s"(rk), "s"(dst) : "memory");
+    }
+  };
+
+  // ---- V staging: thread (kv pair p, 8-d chunk c) for tid < 160; registers -> packed V^T ----
+  const bool vlive = tid < 160;
+  const int vp = tid & 31, vc = tid >> 5;
+  u32x4 vreg[2];
+  // position of kv (within its 32-kv sub-tile) in the V^T row: the 8 k-slots of lane group g' are contiguous,
+  // g' = (quad >> 2) + 2 (quad & 1), slot = 4 ((quad >> 1) & 1) + (kv & 3)   [quad = kv_local >> 2]
+  unsigned vlds;  // byte offset of this thread's word inside a V^T buffer, row 8 c
+  {
+    const int kv = 2 * vp, u = kv >> 5, kl = kv & 31, quad = kl >> 2;
+    const int gg = (quad >> 2) + 2 * (quad & 1), slot = 4 * ((quad >> 1) & 1) + (kl & 3);
+    vlds = (unsigned)(V_OFF + (8 * vc) * VROWB + (32 * u + 8 * gg + slot) * 2);
+  }
+  const unsigned vlds0 = vlive ? vlds : (unsigned)(DUMMY_OFF + 4 * lane);
+  const unsigned vlds1 = vlive ? vlds + VBUF : (unsigned)(DUMMY_OFF + 4 * lane);
+  auto issue_v = [&](int t) {
+    const bool s2 = t >= T0;
+    const uint16_t* vb = s2 ? a.v2 : vb0;
+    const unsigned ldvb = (unsigned)((s2 ? a.ldv2 : a.ldv) * 2);
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldvb), 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kv = kv0 + 2 * vp + r;
+      const bool ok = vlive & (kv < nk);
+      vreg[r] = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (unsigned)kv * ldvb + (unsigned)((head * D + vc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
+    }
+  };
+  auto stage_v = [&](int buf) {  // branch-free, so that it schedules into the shadow of the P.V MFMAs
+    unsigned char* vt = smem + (buf ? vlds1 : vlds0);
+    const uint32_t w0[4] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w};
+    const uint32_t w1[4] = {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<uint32_t*>(vt + (2 * e) * VROWB) = __builtin_amdgcn_perm(w1[e], w0[e], 0x05040100u);
+      *reinterpret_cast<uint32_t*>(vt + (2 * e + 1) * VROWB) = __builtin_amdgcn_perm(w1[e], w0[e], 0x07060302u);
+    }
+  };
+
+  // per-lane fragment addresses inside buffer 0 (loop-invariant); lanes h2 = 1 read K columns 40..47 from the
+  // constant slot, whose address does not move with the buffer
+  const unsigned kaddr = (unsigned)(li * KROWB + 16 * h2);            // + 32 u rows + 32 s bytes
+  const unsigned kaddr2_0 = h2 ? (unsigned)CONST_OFF : kaddr + 64;     // k-step 2, buffer 0
+  const unsigned kaddr2_d = h2 ? 0u : (unsigned)KBUF;                  // ... its step to buffer 1
+  const unsigned vaddr = (unsigned)(V_OFF + i16 * VROWB + 16 * g);    // + 16 dt rows + 64 u bytes
+
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+  // S^T(x) = K.Q^T(x): 32 kv x 32 q per sub-tile u, three k-steps of 16 (the third carries the reference row)
+  auto qk = [&](const uint4 (&kf)[2][3], int x, f32x16 (&st)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) st[u] = HT<DT>::mfma32(kf[u][s], qf[x][s], s == 0 ? zero16 : st[u]);
+  };
+  // exp2 + pack; returns the OR of the packed words (bit 14 of a half set <=> that p >= 2)
+  auto exp_pack = [&](const f32x16 (&st)[2], uint32_t (&w)[2][8]) -> uint32_t {
+    uint32_t orr = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k]), fast_exp2(st[u][2 * k + 1]));
+        orr |= w[u][k];
+      }
+    return orr;
+  };
+  // Slow path of one query block (first tile, overshoot, ragged tile): recompute S, mask, move the reference to
+  // ceil(running max) + HEAD, rescale O, redo exp + pack.  Exact softmax arithmetic; identical to the fast path's
+  // result whenever the fast path is valid.
+  auto slow = [&](const uint4 (&kf)[2][3], int x, int t, int kv0, int nk, uint32_t (&w)[2][8]) {
+    f32x16 st[2];
+    qk(kf, x, st);
+    if (kv0 + KV_TILE > nk) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (kv >= nk) st[u][r] = -INFINITY;
+        }
+    }
+    float mt = st[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[u][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    // st = score - mq; the new reference is ceil(score max) + HEAD, but it never moves down (a lower reference
+    // would need no rescale of O yet buys nothing) except on the first tile, where there is no history
+    float dlt = ceilf(mt) + HEAD;
+    if (t != 0) dlt = fmaxf(dlt, 0.f);
+    if (!(dlt > -4000.f)) dlt = 0.f;  // a fully masked tile (mt = -inf) keeps the reference
+    dlt = fminf(fmaxf(dlt, -2000.f - mq[x]), 2000.f - mq[x]);
+    dlt = HT<DT>::to_f(HT<DT>::from_f(mq[x] + dlt)) - mq[x];  // move by the difference of the STORED halfs
+    if (t != 0) {
+      const float alpha = fast_exp2(-dlt);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float aj = __shfl(alpha, i16 + 16 * j, 64);  // 32x32 view (q = li) -> 16x16 view (q = 16 j + i16)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) ot[x][dt][j] *= aj;
+      }
+    }
+    mq[x] += dlt;
+    if (h2 == 1) qf[x][2].x = (qf[x][2].x & 0xffff0000u) | (uint32_t)HT<DT>::from_f(-mq[x]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k] - dlt), fast_exp2(st[u][2 * k + 1] - dlt));
+  };
+  // packed P words of the 32x32 layout -> B operands of the 16x16x32 MFMA.  w[k] (k < 4) holds kv {0..3, 8..11} + 4 h2
+  // and w[4 + k] kv {16..19, 24..27} + 4 h2 of query li.  Swapping the odd 16-lane rows of w[k] with the even rows of
+  // w[4 + k] leaves in w[k] the fragment of query tile 0 (q = i16) and in w[4 + k] that of query tile 1 (q = 16 + i16);
+  // lane group g then holds the kv set {0, 16, 4, 20}[g] + {0..3, 8..11} — the order V^T is stored in.
+  auto to_frag = [&](uint32_t (&w)[2][8], uint4 (&pf)[2][2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const auto r2 = __builtin_amdgcn_permlane16_swap(w[u][k], w[u][4 + k], false, false);
+        w[u][k] = r2[0];
+        w[u][4 + k] = r2[1];
+      }
+      pf[u][0] = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
+      pf[u][1] = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
+    }
+  };
+  // O^T(x) += V^T.P^T(x): d tiles {0..15, 16..31, 32..47}, two k-steps of 32 kv
+  auto pv = [&](const unsigned char* vbuf, int x, const uint4 (&pf)[2][2]) {
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(vbuf + dt * 16 * VROWB + 64 * u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ot[x][dt][j] = HT<DT>::mfma16(vf, pf[u][j], ot[x][dt][j]);
+      }
+  };
+
+  // ---- one KV tile; CUR (the LDS buffer pair it reads) is a compile-time constant ----
+  auto tile = [&](auto cur_c, int t) {
+    constexpr int CUR = decltype(cur_c)::value;
+    if (t + 1 < T) dma_k(t + 1, CUR ^ 1);  // buffer CUR^1 was last read in iteration t-1 (barrier passed)
+    const bool s2 = t >= T0;
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const bool special = (t == 0) | (kv0 + KV_TILE > nk);  // wave-uniform: first / ragged tiles take the slow path
+    const unsigned char* kbuf = smem + CUR * KBUF;
+    const unsigned char* vbuf = smem + CUR * VBUF + vaddr;
+
+    uint4 kf[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB);
+      kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB + 32);
+      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + CUR * kaddr2_d + (h2 ? 0 : u * 32 * KROWB));
+    }
+    f32x16 sa[2], sb[2];
+    uint32_t wa[2][8], wb[2][8];
+    uint4 pa[2][2], pb[2][2];
+    if (ORDER == 0 || ORDER == 2) {
+      // QK^T(A) | QK^T(B) + softmax(A) | P.V(A) + softmax(B) | P.V(B) + staging
+      qk(kf, 0, sa);
+      qk(kf, 1, sb);
+      const uint32_t ora = exp_pack(sa, wa);
+      if (ORDER == 2) {  // pin the interleave: QK^T(A) back to back, then one QK^T(B) MFMA per 9 softmax(A) instructions
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
+      to_frag(wa, pa);
+      const uint32_t orb = exp_pack(sb, wb);
+      pv(vbuf, 0, pa);
+      if (ORDER == 2) {  // one P.V(A) MFMA per 5 softmax(B) instructions
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
+      to_frag(wb, pb);
+    } else {
+      // plain order: both QK^T, both softmaxes, both P.V
+      qk(kf, 0, sa);
+      qk(kf, 1, sb);
+      const uint32_t ora = exp_pack(sa, wa);
+      const uint32_t orb = exp_pack(sb, wb);
+      if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
+      if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
+      to_frag(wa, pa);
+      to_frag(wb, pb);
+      pv(vbuf, 0, pa);
+    }
+    if (t + 1 < T) stage_v(CUR ^ 1);                      // tile t+1 (in registers) -> the other V^T buffer
+    pv(vbuf, 1, pb);
+    if (t + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's K(t+1) DMA has landed
+      if (t + 2 < T) issue_v(t + 2);
+      __syncthreads();                                    // publishes tile t+1; every wave is done with buffers CUR
+    }
+  };
+
+  // ---- pipeline: K(t+1) DMA and V(t+1) staging + V(t+2) loads run under the MFMAs of tile t; ONE barrier per tile ----
+  dma_k(0, 0);
+  issue_v(0);
+  __syncthreads();  // orders the LDS init
+  stage_v(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (T > 1) issue_v(1);
+  __syncthreads();
+
+  for (int t = 0; t < T; t += 2) {
+    tile(IC2<0>{}, t);
+    if (t + 1 < T) tile(IC2<1>{}, t + 1);
+  }
+
+  // ---- epilogue: denominators from the ones-row (d = 40: tile 2, row 8 -> lane group 2, register 0) ----
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float den = __shfl(ot[x][2][j][0], 32 + i16, 64);
+      const float inv = den > 0.f ? 1.f / den : 0.f;
+      const int qr = q0 + 32 * x + 16 * j + i16;
+      if (qr < a.Nq) {
+        uint16_t* op = a.out + ((int64_t)b * a.Nq + qr) * a.ldo + head * D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          if (dt == 2 && g >= 2) continue;  // rows 40..47 are not output columns
+          uint2 o;
+          o.x = pack2<DT>(ot[x][dt][j][0] * inv, ot[x][dt][j][1] * inv);
+          o.y = pack2<DT>(ot[x][dt][j][2] * inv, ot[x][dt][j][3] * inv);
+          *reinterpret_cast<uint2*>(op + 16 * dt) = o;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Temporal attention: one wave per (batch b, pixel p, head h); sequence = F <= 32 frames.
 // ------------------------------------------------------------------------------------
 struct TAttnArgs {
@@ -492,6 +876,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int6
 
 }  // namespace
 
+static inline bool attn40_legacy() { return tune_env("MIMO_ATTN40_LEGACY", 0) != 0; }
+template <int DT>
+static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)(((a.Nq + 255) / 256) * a.heads * a.B));
+  const int order = tune_env("MIMO_ATTN40_ORDER", 0);
+  if (order == 1) hipLaunchKernelGGL((attn40_kernel<DT, 1>), grid, dim3(256), 0, st, a);
+  else if (order == 2) hipLaunchKernelGGL((attn40_kernel<DT, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn40_kernel<DT, 0>), grid, dim3(256), 0, st, a);
+}
+
 extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
                               const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
                               int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
@@ -513,7 +907,9 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
 #define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD, false>), grid, dim3(256), 0, st, a)
 #define ATTN_LAUNCH40(DT)                                                                          \
   do {                                                                                             \
-    if (a.prescaled) hipLaunchKernelGGL((attn_kernel<DT, 40, true>), grid, dim3(256), 0, st, a);   \
+    if (a.prescaled && !attn40_legacy())                                                           \
+      attn40_launch<DT>(a, st);                                                                    \
+    else if (a.prescaled) hipLaunchKernelGGL((attn_kernel<DT, 40, true>), grid, dim3(256), 0, st, a);   \
     else hipLaunchKernelGGL((attn_kernel<DT, 40, false>), grid, dim3(256), 0, st, a);              \
   } while (0)
   if (dtype == MIMO_F16) {

@@ -126,6 +126,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + slot;
 }
 
+// Tuning knobs exist only in the -DMIMO_TUNE build (libmimo_hip_tune.so, tools/microbench.py): the shipped library
+// reads no environment and has no mutable global state; every knob folds to its default at compile time.
+#ifdef MIMO_TUNE
+#include <stdlib.h>
+inline int tune_env(const char* key, int dflt) {
+  const char* v = getenv(key);
+  return v ? atoi(v) : dflt;
+}
+#else
+constexpr int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 #define MIMO_LAUNCH_CHECK()                    \
   do {                                         \
     hipError_t e__ = hipGetLastError();        \

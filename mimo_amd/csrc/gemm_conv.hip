@@ -28,6 +28,16 @@ namespace {
 
 constexpr int BK = 64;
 
+// internal launch flags (upper half of GemmArgs::flags; the public MIMO_EPI_* bits live in the lower half)
+constexpr unsigned F_STAGGER = 0x40000u;    // waves sharing a SIMD issue their DMAs at different points of the K-tile
+constexpr unsigned F_TAP_INNER = 0x80000u;  // convolution K order: channel chunk outer, tap inner
+#ifdef MIMO_TUNE  // timing experiments of tools/microbench.py (results are wrong): never compiled into the shipped library
+#define MIMO_ABLATE(g, bit) (((g).flags & (bit)) != 0u)
+#else
+#define MIMO_ABLATE(g, bit) false
+#endif
+constexpr unsigned F_ABL_NO_DMA = 0x10000u, F_ABL_NO_MFMA = 0x20000u, F_ABL_NO_GELU = 0x100000u;
+
 struct GemmArgs {
   const uint16_t* A;
   const uint16_t* A2;
@@ -49,6 +59,15 @@ struct GemmArgs {
   int Hin, Win, Cin, Hout, Wout, ks, stride, pad_t, pad_l, Hup, Wup, Cin2;
   float sh, sw;
   int chunks1, chunks2, nkt;
+  // optional fused side outputs (mimo_epilogue_ext)
+  float* colstats;       // [M/32][2][N]: per 32-row slab and column (mean, centred sum of squares) of the stored values
+  const float* ln_gamma; // LayerNorm over the N columns of every output row (needs N == tile width): gamma, beta [N]
+  const float* ln_beta;
+  const float* ln_pe;    // optional additive table [pe_frames][N], row = (m / ln_rows_per_frame) % ln_pe_frames
+  void* ln_out;          // half16 [M, N] (ld = N)
+  float ln_eps;
+  int64_t ln_rows_per_frame;
+  int ln_pe_frames;
 };
 
 template <int V>
@@ -144,7 +163,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           const int ng = (ni + 1 < NR) ? ni + 1 : ni;
           const f32x4 gt = acc[ng][mi] + bv[ng];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= (g.flags & 0x100000u) ? gt[r] : gelu_erf_f(gt[r]);  // (ablation: no GELU)
+          for (int r = 0; r < 4; ++r) v[r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
         }
         if (do_silu) {
 #pragma unroll
@@ -172,8 +191,257 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
   else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
 }
 
+
+// sum over the 16 lanes of a DPP row (= the 16 rows `li` of one MFMA tile that share a column chunk): four
+// v_add_f32_dpp, every lane ends up with the total, fixed order (deterministic)
+__device__ __forceinline__ float row16_sum(float x) {
+  auto dpp = [](float v, auto ctrl_c) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+  };
+  x += dpp(x, IC<0xB1>{});   // quad_perm [1,0,3,2]
+  x += dpp(x, IC<0x4E>{});   // quad_perm [2,3,0,1]
+  x += dpp(x, IC<0x141>{});  // row_half_mirror
+  x += dpp(x, IC<0x140>{});  // row_mirror
+  return x;
+}
+
+// ---- epilogue variant that also emits GroupNorm column statistics ----
+// GroupNorm statistics of the tensor this launch writes are produced HERE, from the fp32 values in registers,
+// instead of by a second pass over HBM: for every 32-row slab (two MFMA row tiles) and every column the epilogue
+// writes (mean, sum of squared deviations from that mean) — an exact two-pass computation inside the slab — and
+// mimo_group_norm_stats_cols merges the slabs of an image and the columns of a group (Chan's parallel update, in
+// double, fixed order).  Loop order: slab outer, column group inner, so only two row tiles of values are live.
+template <int DT, int NR, int MT, int BM>
+__device__ __forceinline__ void tile_epilogue_stats(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0, const int N0,
+                                                    const int wm, const int wn, const int lg, const int li) {
+  static_assert(MT % 2 == 0, "32-row slabs");
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
+  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
+  const bool do_silu = g.flags & MIMO_EPI_SILU;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.out + M0 * g.ldo * esz_o, 0, (int)(((rows_valid - 1) * g.ldo + g.N) * esz_o), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
+      g.res ? (int)(((rows_valid - 1) * g.ldr + g.N) * esz_r) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
+  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
+  // colstats rows of this tile: slab index (M0 + row) / 32, two planes of N floats each
+  const int64_t slab0 = M0 >> 5;
+  const int64_t slabs_valid = (rows_valid + 31) >> 5;
+  const __amdgpu_buffer_rsrc_t r_cs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.colstats + slab0 * 2 * g.N), 0, (int)(slabs_valid * 2 * g.N * 4), 0x00020000);
+  const int row0 = wm * 16 * MT + li;
+  const int col0 = wn * 16 * NR + 4 * lg;
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+#pragma unroll
+  for (int sp = 0; sp < MT / 2; ++sp) {
+    const unsigned rowa = (unsigned)(row0 + (2 * sp) * 16), rowb = rowa + 16u;
+    unsigned imga = 0, imgb = 0;
+    if (g.img_bias) {
+      imga = ((unsigned)(M0 + rowa) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+      imgb = ((unsigned)(M0 + rowb) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+    }
+    const unsigned slab_local = (unsigned)((wm * 16 * MT) >> 5) + (unsigned)sp;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const int n = N0 + col0 + ni * 16;
+      const bool ok = n < g.N;
+      const f32x4 bv = ld4(r_bias, ok ? (unsigned)n * 4u : OOB);
+      f32x4 va = acc[ni][2 * sp] + bv, vb = acc[ni][2 * sp + 1] + bv;
+      if (g.img_bias) {
+        va += ld4(r_imgb, ok ? imga + (unsigned)n * 4u : OOB);
+        vb += ld4(r_imgb, ok ? imgb + (unsigned)n * 4u : OOB);
+      }
+      if (do_silu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { va[r] = silu_f(va[r]); vb[r] = silu_f(vb[r]); }
+      }
+      if (g.res) {
+        if (res_f32) {
+          va += ld4(r_res, ok ? (rowa * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
+          vb += ld4(r_res, ok ? (rowb * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
+        } else {
+          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, ok ? (rowa * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, ok ? (rowb * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+          va += (f32x4){HT<DT>::to_f((uint16_t)(ha.x & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.x >> 16)),
+                        HT<DT>::to_f((uint16_t)(ha.y & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.y >> 16))};
+          vb += (f32x4){HT<DT>::to_f((uint16_t)(hb.x & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.x >> 16)),
+                        HT<DT>::to_f((uint16_t)(hb.y & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.y >> 16))};
+        }
+      }
+      va *= g.out_scale;
+      vb *= g.out_scale;
+      const unsigned oa = ok ? (rowa * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
+      const unsigned ob = ok ? (rowb * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
+      if (out_f32) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va), r_out, oa, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), r_out, ob, 0, 0);
+      } else {
+        u32x2 o;
+        o.x = pack2<DT>(va[0], va[1]); o.y = pack2<DT>(va[2], va[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, oa, 0, 0);
+        o.x = pack2<DT>(vb[0], vb[1]); o.y = pack2<DT>(vb[2], vb[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ob, 0, 0);
+      }
+      // slab statistics of this column chunk: 32 rows = (rows li of tile a) + (rows li of tile b)
+      f32x4 mean, m2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mean[r] = row16_sum(va[r] + vb[r]) * (1.0f / 32.0f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float da = va[r] - mean[r], db = vb[r] - mean[r];
+        m2[r] = row16_sum(fmaf(da, da, db * db));
+      }
+      const unsigned cso = (ok && li == 0) ? (slab_local * 2u * (unsigned)g.N + (unsigned)n) * 4u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean), r_cs, cso, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m2), r_cs, cso == OOB ? OOB : cso + (unsigned)g.N * 4u, 0, 0);
+    }
+  }
+}
+
+// ---- epilogue variant with a fused LayerNorm second output (the tile holds whole rows: BN == N) ----
+// out[m, :] = acc + bias (+ per-image bias) (+ residual)  stored as usual (the fp32 residual stream), and
+// ln_out[m, :] = LayerNorm(out[m, :]) * gamma + beta (+ pe[frame]) stored as half: the operand of the next GEMM.
+// Replaces a separate LayerNorm launch that re-read the fp32 tensor from HBM.  Row statistics are exact two-pass
+// (mean, then centred sum of squares), fp32; a row is spread over the WN waves of a block row, so the partial sums meet
+// in LDS (`red`: 2 x BM x WN floats).
+template <int DT, int NR, int MT, int BM, int WN>
+__device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0,
+                                                 const int wm, const int wn, const int lg, const int li, float* red) {
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const bool out_f32 = g.flags & MIMO_EPI_OUT_F32;
+  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.out + M0 * g.ldo * esz_o, 0, (int)(((rows_valid - 1) * g.ldo + g.N) * esz_o), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
+      g.res ? (int)(((rows_valid - 1) * g.ldr + g.N) * esz_r) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
+  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_ln = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.ln_out + M0 * g.N * 2, 0, (int)(rows_valid * g.N * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_gam = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.ln_gamma), 0, g.N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bet = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.ln_beta), 0, g.N * 4, 0x00020000);
+  // the whole tile lies in one frame (host: ln_rows_per_frame % BM == 0)
+  const int64_t frame = g.ln_pe ? (M0 / g.ln_rows_per_frame) % g.ln_pe_frames : 0;
+  const __amdgpu_buffer_rsrc_t r_pe = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.ln_pe ? g.ln_pe + frame * g.N : nullptr), 0, g.ln_pe ? g.N * 4 : 0, 0x00020000);
+  const int row0 = wm * 16 * MT + li;
+  const int col0 = wn * 16 * NR + 4 * lg;
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+  // ---- 1: the ordinary epilogue; the stored values stay in `acc` ----
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const unsigned n = (unsigned)(col0 + ni * 16);
+    const f32x4 bv = ld4(r_bias, n * 4u);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const unsigned row = (unsigned)(row0 + mi * 16);
+      f32x4 v = acc[ni][mi] + bv;
+      if (g.img_bias) v += ld4(r_imgb, ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + n * 4u);
+      if (g.res) {
+        if (res_f32) {
+          v += ld4(r_res, (row * (unsigned)g.ldr + n) * 4u);
+        } else {
+          const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, (row * (unsigned)g.ldr + n) * 2u, 0, 0);
+          v += (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
+                       HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+        }
+      }
+      v *= g.out_scale;
+      acc[ni][mi] = v;
+      const unsigned ooff = (row * (unsigned)g.ldo + n) * esz_o;
+      if (out_f32) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+      } else {
+        u32x2 o;
+        o.x = pack2<DT>(v[0], v[1]); o.y = pack2<DT>(v[2], v[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+      }
+    }
+  }
+  // ---- 2: row means.  A lane holds 4 NR values of each of its MT rows; the 4 lane groups lg and the WN waves hold the rest ----
+  const float invn = 1.0f / (float)g.N;
+  float mean[MT], rstd[MT];
+  auto row_reduce = [&](float (&s)[MT], float* redp) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      s[mi] += __shfl_xor(s[mi], 16, 64);
+      s[mi] += __shfl_xor(s[mi], 32, 64);
+      if (lg == 0) redp[(wm * 16 * MT + mi * 16 + li) * WN + wn] = s[mi];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const float* rp = redp + (wm * 16 * MT + mi * 16 + li) * WN;
+      float t = rp[0];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) t += rp[w];  // fixed order
+      s[mi] = t;
+    }
+  };
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    float t = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) t += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
+    mean[mi] = t;
+  }
+  row_reduce(mean, red);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) mean[mi] *= invn;
+  // ---- 3: centred sums of squares ----
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    float t = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[ni][mi][r] - mean[mi];
+        t = fmaf(d, d, t);
+      }
+    rstd[mi] = t;
+  }
+  row_reduce(rstd, red + BM * WN);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) rstd[mi] = rsqrtf(rstd[mi] * invn + g.ln_eps);
+  // ---- 4: normalise, affine (+ positional table), store half ----
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const unsigned n = (unsigned)(col0 + ni * 16);
+    const f32x4 gm = ld4(r_gam, n * 4u), bt = ld4(r_bet, n * 4u) + ld4(r_pe, g.ln_pe ? n * 4u : OOB);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const unsigned row = (unsigned)(row0 + mi * 16);
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[ni][mi][r] - mean[mi]) * rstd[mi], gm[r], bt[r]);
+      u32x2 o;
+      o.x = pack2<DT>(y[0], y[1]); o.y = pack2<DT>(y[2], y[3]);
+      __builtin_amdgcn_raw_buffer_store_b64(o, r_ln, (row * (unsigned)g.N + n) * 2u, 0, 0);
+    }
+  }
+}
+
 // MODE 0: dense GEMM; 1: convolution gather; 2: convolution gather through a nearest-neighbour upsampling
-template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE, int MT>
+// EPI 0: ordinary epilogue (+ GroupNorm column statistics when g.colstats is set); 1: + fused LayerNorm second output
+template <int DT, int NR, int MODE, int WM, int WN, int NSTAGE, int MT, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const GemmArgs g) {
   constexpr bool CONV = MODE != 0;
   constexpr int THREADS = 64 * WM * WN;
@@ -186,8 +454,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   constexpr int LOADS = NAJ + NBJ;                    // DMAs per thread per K-tile
   static_assert(BM % PASS == 0, "A tile must be a whole number of DMA passes");
   constexpr int STAGE = (BM + BNA) * 8;               // 16-byte units per ring slot: [A tile | B tile]
+  constexpr int LNRED = EPI == 1 ? (2 * BM * WN) / 4 : 0;  // 16-byte units of the LayerNorm row-sum exchange
   // ONE LDS object (a second __shared__ array would make hipcc drain vmcnt before fragment reads)
-  __shared__ __attribute__((aligned(16))) uint4 smem[NSTAGE * STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 smem[NSTAGE * STAGE + LNRED];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -282,7 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
         // K order: channel chunk outer, tap inner (flag 0x80000) -> the 9 shifted re-reads of one input chunk are
         // consecutive K-tiles and hit in L2; or tap outer, chunk inner
         const int ntaps = g.ks * g.ks;
-        const bool tap_inner = g.flags & 0x80000u;
+        const bool tap_inner = g.flags & F_TAP_INNER;
         const int tap = tap_inner ? kt % ntaps : kt / g.chunks1;
         const int c0 = (tap_inner ? kt / ntaps : kt - tap * g.chunks1) * BK;
         const int ky = tap / g.ks, kx = tap - ky * g.ks;
@@ -353,7 +622,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   };
   // Waves that share a SIMD (w, w+4, ...) issue their DMAs at different points of the K-tile, so that a
   // SIMD's matrix pipe is not left idle while all of its waves sit in the (slow-to-issue) DMA instructions.
-  const bool late = (g.flags & 0x40000u) && ((wave >> 2) & 1);
+  const bool late = (g.flags & F_STAGGER) && ((wave >> 2) & 1);
 
   // One K-tile: wait until everything but the newest NSTAGE-2 tiles of THIS wave has landed, barrier (all
   // waves' parts landed AND every wave is done reading the slot about to be recycled), refill that slot with
@@ -362,7 +631,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
     constexpr int S = decltype(slot_c)::value;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
     __syncthreads();
-    const bool dma_on = !(g.flags & 0x10000u), mfma_on = !(g.flags & 0x20000u);  // (ablation switches)
+    const bool dma_on = !MIMO_ABLATE(g, F_ABL_NO_DMA), mfma_on = !MIMO_ABLATE(g, F_ABL_NO_MFMA);
     if (dma_on && !late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
     if (mfma_on) compute(slot_c, 0);
     if (dma_on && late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
@@ -378,7 +647,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 
-  tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
+  if constexpr (EPI == 1) {
+    tile_epilogue_ln<DT, NR, MT, BM, WN>(g, acc, M0, wm, wn, lg, li, reinterpret_cast<float*>(&smem[NSTAGE * STAGE]));
+  } else {
+    if constexpr (WM * WN <= 8) {  // (the 16-wave tiles have a 128-register budget: no room for a second epilogue)
+      if (g.colstats) {
+        tile_epilogue_stats<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li);
+        return;
+      }
+    }
+    tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
+  }
 }
 
 // Persistent dense GEMM (MODE 0, 2-deep ring): the grid is ONE resident set of blocks; block b walks tiles b, b + grid, ...
@@ -386,7 +665,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
 // output tile lands under the last MFMAs and the epilogue of the current one (short-K linears: K = 320 is five K-tiles
 // per output tile and paid a full L2/HBM round trip plus a block launch per tile).  The loader keeps two VGPRs of state:
 // per-tile geometry lives in the (scalar) buffer descriptors, clipped to the tile's valid rows.
-template <int DT, int NR, int WM, int WN, int MT>
+template <int DT, int NR, int WM, int WN, int MT, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persist_kernel(const GemmArgs g) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int BM = 16 * MT * WM;
@@ -397,7 +676,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
   constexpr int BNA = NBJ * PASS > BN ? BN + 8 : BN;
   static_assert(BM % PASS == 0, "A tile must be a whole number of DMA passes");
   constexpr int STAGE = (BM + BNA) * 8;
-  __shared__ __attribute__((aligned(16))) uint4 smem[2 * STAGE];
+  constexpr int LNRED = EPI == 1 ? (2 * BM * WN) / 4 : 0;
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * STAGE + LNRED];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -463,7 +743,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
       set_tile(ld_v);
     }
   };
-  const bool late = (g.flags & 0x40000u) && ((wave_u >> 2) & 1);
+  const bool late = (g.flags & F_STAGGER) && ((wave_u >> 2) & 1);
 
   issue(0);
   int slot = 0;
@@ -503,7 +783,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
     const int N0 = (int)(Lc % (unsigned)g.tiles_n) * BN;
     int lg_ = lg, li_ = li;
     asm volatile("" : "+v"(lg_), "+v"(li_));  // keeps the epilogue's lane-invariant address math inside the tile loop
-    tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
+    if constexpr (EPI == 1) {
+      tile_epilogue_ln<DT, NR, MT, BM, WN>(g, acc, M0, wm, wn, lg_, li_, reinterpret_cast<float*>(&smem[2 * STAGE]));
+    } else {
+      tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
 }
@@ -554,25 +838,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, in
   }
 }
 
-// Tuning knobs, read from the environment once (mimo_reload_tuning() re-reads them; tools/microbench.py --ab):
+// Tuning knobs.  In the shipped build they are compile-time constants (tune_env folds to its default: the library
+// reads no environment and keeps no mutable state).  Only the -DMIMO_TUNE build (libmimo_hip_tune.so, used by
+// tools/microbench.py for interleaved A/B timing) reads them from the environment, at every launch:
 //   MIMO_GEMM_CFG=1|2|3|4   force tile configuration S|L|XL|XL8
 //   MIMO_GEMM_STAGGER=0     all waves issue their DMAs right after the barrier (default 1: staggered)
 //   MIMO_CONV_TAP_INNER=0   convolution K order tap-outer / channel-chunk-inner (default 1: tap inner)
 //   MIMO_GEMM_BM=256|192|128  force the XL8 tile height (default: picked per shape by wave quantisation)
 //   MIMO_GEMM_PERSIST=0     dense GEMMs launch one block per output tile (default 1: persistent blocks, cross-tile prefetch)
-//   MIMO_GEMM_SPLITK=0      never split K (default 1: long-K problems with too few tiles for the chip are split)
+//   MIMO_GEMM_SPLITK=0      never split K (default 1; per call: MIMO_EPI_NO_SPLITK)
 //   MIMO_GEMM_ABLATE=1|2|3  timing experiments: skip DMA | skip MFMA | skip GELU (results are wrong)
 struct Tuning {
   int cfg, ablate, stagger, tap_inner, splitk, bm, persist;
 };
-Tuning read_tuning() {
-  auto env = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
-  return Tuning{env("MIMO_GEMM_CFG", 0), env("MIMO_GEMM_ABLATE", 0), env("MIMO_GEMM_STAGGER", 1), env("MIMO_CONV_TAP_INNER", 1),
-                env("MIMO_GEMM_SPLITK", 1), env("MIMO_GEMM_BM", 0), env("MIMO_GEMM_PERSIST", 1)};
+inline Tuning tuning() {
+  return Tuning{tune_env("MIMO_GEMM_CFG", 0), tune_env("MIMO_GEMM_ABLATE", 0), tune_env("MIMO_GEMM_STAGGER", 1),
+                tune_env("MIMO_CONV_TAP_INNER", 1), tune_env("MIMO_GEMM_SPLITK", 1), tune_env("MIMO_GEMM_BM", 0),
+                tune_env("MIMO_GEMM_PERSIST", 1)};
 }
-Tuning& tuning() {
-  static Tuning t = read_tuning();
-  return t;
+
+// CU count of the current device: an immutable fact of the hardware, cached after the first query
+inline int cus_() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return cus;
 }
 
 template <int DT, int MODE, int NR>
@@ -583,11 +876,11 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   //   XL 4x4, 2 stages: 256 x 64NR tile (N = 320 in ONE tile), 16 waves, 1 block/CU — halves the global->LDS
   //      bytes per MAC; the L2->LDS path (~18 TB/s measured) and not the MFMAs bounds the S tile
   //   XL8 2x4, 2 stages: the XL tile on 8 waves of 128 x 16NR (256-register budget) — every NR = 5 XL problem
-  const Tuning& tn = tuning();
+  const Tuning tn = tuning();
   const int forced = tn.cfg, ablate = tn.ablate;
-  if (ablate == 1) g.flags |= 0x10000u;
-  if (ablate == 2) g.flags |= 0x20000u;
-  if (ablate == 3) g.flags |= 0x100000u;
+  if (ablate == 1) g.flags |= F_ABL_NO_DMA;
+  if (ablate == 2) g.flags |= F_ABL_NO_MFMA;
+  if (ablate == 3) g.flags |= F_ABL_NO_GELU;
   const int64_t m256 = (g.M + 255) / 256;
   const int tn_s = (g.N + 32 * NR - 1) / (32 * NR), tn_xl = (g.N + 64 * NR - 1) / (64 * NR);
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
@@ -596,19 +889,31 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     if (g.N <= 32 * NR) cfg = (m256 * tn_s >= 160) ? 2 : 1;  // one S-width tile covers N: a 64NR-wide XL tile would idle
     else cfg = (m256 * tn_xl >= 160) ? 3 : 1;                 // measured crossover (tools/microbench.py)
   }
-  if (tn.stagger) g.flags |= 0x40000u;
-  if (tn.tap_inner && MODE != 0) g.flags |= 0x80000u;
+  if (tn.stagger) g.flags |= F_STAGGER;
+  if (tn.tap_inner && MODE != 0) g.flags |= F_TAP_INNER;
   if (cfg == 3 && NR == 5) cfg = 4;  // 16 waves x 128 registers cannot hold a 64 x 80 accumulator tile plus the epilogue
+  if (cfg == 3 && g.colstats) cfg = 4;  // the 16-wave tile has no statistics epilogue
+  const bool allow_splitk = tn.splitk && !(g.flags & MIMO_EPI_NO_SPLITK) && !g.colstats && !g.ln_out;
+  // fused LayerNorm output: the tile must hold whole rows (N == 320 = the NR = 5 XL8 width), dense only
+  if (g.ln_out) {
+    if constexpr (MODE == 0 && NR == 5) {
+      if (g.N != 64 * NR || geglu || g.colstats) return MIMO_EINVAL;
+      g.tiles_n = 1;
+      const int64_t nwg = (g.M + 127) / 128;
+      if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+      g.ntiles = (unsigned)nwg;
+      hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 2, 4, 4, 1>), dim3((unsigned)(nwg < cus_() ? nwg : cus_())), dim3(512), 0, st, g);
+      MIMO_LAUNCH_CHECK();
+      return MIMO_OK;
+    } else {
+      return MIMO_EINVAL;
+    }
+  }
   // Split-K: a long reduction over few output tiles (the 8x8-level convolutions: M = 3072, K = 11520) leaves most of
   // the chip idle.  Use XL8 tiles, split K over gridDim.y, and let a second tiny launch reduce the fp32 partials
   // (fixed order) and apply the epilogue.  Needs the caller's workspace.
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  if (forced == 0 && tn.splitk && !geglu && g.ws && NR == 5) {
+  const int cus = cus_();
+  if (forced == 0 && allow_splitk && !geglu && g.ws && NR == 5) {
     const int64_t nt = m256 * tn_xl;
     int64_t sk = nt > 0 ? cus / nt : 0;
     if (sk > g.nkt / 16) sk = g.nkt / 16;
@@ -647,7 +952,7 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
     // persistent blocks pay off (measured +2..7 %) for short reductions over many rounds of tiles — the level-0 linears;
     // with 2-3 exactly filled rounds or long K the plain launch is faster (tools/microbench.py --ab MIMO_GEMM_PERSIST=0)
-    if (MODE == 0 && tn.persist && bm == 256 && nwg >= 3 * (int64_t)cus && g.nkt >= 2 && g.nkt <= 20) {
+    if (MODE == 0 && tn.persist && !g.colstats && bm == 256 && nwg >= 3 * (int64_t)cus && g.nkt >= 2 && g.nkt <= 20) {
       g.ntiles = (unsigned)nwg;
       hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 2, 4, 8>), dim3((unsigned)cus), dim3(512), 0, st, g);
       MIMO_LAUNCH_CHECK();
@@ -697,14 +1002,35 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
-                         int64_t M, int N, int K, const float* bias, const float* img_bias,
-                         int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
-                         float out_scale, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+static int check_ext(const mimo_epilogue_ext* e, GemmArgs& g, int64_t M, int N, unsigned flags) {
+  g.colstats = nullptr; g.ln_gamma = g.ln_beta = g.ln_pe = nullptr; g.ln_out = nullptr;
+  g.ln_eps = 0.f; g.ln_rows_per_frame = 1; g.ln_pe_frames = 1;
+  if (!e) return MIMO_OK;
+  if (e->colstats) {
+    if ((M & 31) || (N & 3) || (flags & MIMO_EPI_GEGLU) || !aligned16(e->colstats)) return MIMO_EINVAL;
+    g.colstats = e->colstats;
+  }
+  if (e->ln_out) {
+    if (!e->ln_gamma || !e->ln_beta || e->colstats || !aligned16(e->ln_out)) return MIMO_EINVAL;
+    if (e->ln_pe && (e->ln_rows_per_frame <= 0 || e->ln_pe_frames <= 0 || (e->ln_rows_per_frame % 128))) return MIMO_EINVAL;
+    g.ln_gamma = e->ln_gamma; g.ln_beta = e->ln_beta; g.ln_pe = e->ln_pe; g.ln_out = e->ln_out;
+    g.ln_eps = e->ln_eps;
+    g.ln_rows_per_frame = e->ln_pe ? e->ln_rows_per_frame : 1;
+    g.ln_pe_frames = e->ln_pe ? e->ln_pe_frames : 1;
+  }
+  return MIMO_OK;
+}
+
+extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+                             int64_t M, int N, int K, const float* bias, const float* img_bias,
+                             int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
+                             float out_scale, unsigned flags, void* workspace, size_t workspace_bytes,
+                             const mimo_epilogue_ext* ext, void* stream) {
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return MIMO_EINVAL;
   if ((K & 7) || (lda & 7) || (N & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out))
     return MIMO_EINVAL;
   if ((flags & MIMO_EPI_GEGLU) && (N & 31)) return MIMO_EINVAL;
+  if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_GEGLU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32 | MIMO_EPI_NO_SPLITK)) return MIMO_EINVAL;
   if (residual && (ldr & 3)) return MIMO_EINVAL;
   if (img_bias && (rows_per_img <= 0 || (img_bias_ld & 3))) return MIMO_EINVAL;
   GemmArgs g{};
@@ -715,6 +1041,8 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
   g.ws = aligned16(workspace) ? workspace : nullptr; g.ws_bytes = workspace_bytes;
   g.nkt = (K + BK - 1) / BK;
+  if (int rc = check_ext(ext, g, M, N, flags)) return rc;
+  if (g.ln_out && ((flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || ldo != N || (residual && ldr != N))) return MIMO_EINVAL;
   const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
   if (ab >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;  // operands are addressed with 32-bit offsets
   g.a_bytes = (unsigned)ab; g.a2_bytes = 0; g.w_bytes = (unsigned)wb;
@@ -724,17 +1052,26 @@ extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, v
   return MIMO_EDTYPE;
 }
 
-extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
-                           const mimo_conv_params* p, const float* bias, const float* img_bias,
-                           const void* residual, float out_scale, unsigned flags, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+extern "C" int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
+                         int64_t M, int N, int K, const float* bias, const float* img_bias,
+                         int64_t img_bias_ld, int64_t rows_per_img, const void* residual, int64_t ldr,
+                         float out_scale, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  return mimo_gemm_ext(dtype, A, lda, W, out, ldo, M, N, K, bias, img_bias, img_bias_ld, rows_per_img, residual, ldr,
+                       out_scale, flags, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const void* W, void* out,
+                               const mimo_conv_params* p, const float* bias, const float* img_bias,
+                               const void* residual, float out_scale, unsigned flags, void* workspace,
+                               size_t workspace_bytes, const mimo_epilogue_ext* ext, void* stream) {
   if (!in || !W || !out || !p) return MIMO_EINVAL;
   if (p->n <= 0 || p->Cin <= 0 || (p->Cin & 7) || (p->Cout & 3) || p->Cout <= 0) return MIMO_EINVAL;
   if (!(p->ksize == 1 || p->ksize == 3) || !(p->stride == 1 || p->stride == 2)) return MIMO_EINVAL;
   if (p->Cin2 < 0 || (p->Cin2 & 7) || (p->Cin2 > 0 && !in2)) return MIMO_EINVAL;
   if ((p->Hup > 0) != (p->Wup > 0)) return MIMO_EINVAL;
-  if (flags & MIMO_EPI_GEGLU) return MIMO_EINVAL;
+  if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32 | MIMO_EPI_NO_SPLITK)) return MIMO_EINVAL;
   if (!aligned16(in) || !aligned16(W) || !aligned16(out) || (in2 && !aligned16(in2))) return MIMO_EINVAL;
+  if (ext && ext->ln_out) return MIMO_EINVAL;  // the fused LayerNorm output exists for dense GEMMs only
   GemmArgs g{};
   g.A = (const uint16_t*)in; g.A2 = (const uint16_t*)in2; g.W = (const uint16_t*)W; g.out = out;
   g.bias = bias; g.img_bias = img_bias; g.res = residual;
@@ -754,6 +1091,7 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   g.chunks1 = (p->Cin + BK - 1) / BK;
   g.chunks2 = (p->Cin2 + BK - 1) / BK;
   g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
+  if (int rc = check_ext(ext, g, g.M, g.N, flags)) return rc;
   {
     const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
     if (ab >= 0xFFFFFFF0LL || a2b >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;
@@ -766,11 +1104,17 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
   return MIMO_EDTYPE;
 }
 
-extern "C" int mimo_version(void) { return 4; }
+extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void* out,
+                           const mimo_conv_params* p, const float* bias, const float* img_bias,
+                           const void* residual, float out_scale, unsigned flags, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return mimo_conv2d_ext(dtype, in, in2, W, out, p, bias, img_bias, residual, out_scale, flags, workspace,
+                         workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mimo_version(void) { return 5; }
 
 extern "C" size_t mimo_workspace_bytes(void) { return (size_t)8 * ((size_t)1 << 22) * sizeof(float); }
 
-extern "C" int mimo_reload_tuning(void) {
-  tuning() = read_tuning();
-  return MIMO_OK;
-}
+// Kept for tools/microbench.py: the tune build re-reads its knobs at every launch, the shipped build has none.
+extern "C" int mimo_reload_tuning(void) { return MIMO_OK; }

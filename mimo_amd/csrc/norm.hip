@@ -2,8 +2,10 @@
 //   GroupNorm statistics + apply(+SiLU) over a virtual channel concat of two sources,
 //   LayerNorm (+ temporal positional-encoding add), casts.
 // Reference ops replaced: see include/mimo_hip.h.
-// All are streaming kernels: 16-byte vector loads, fp32 statistics (two-pass centred
-// variance, matching torch's numerics closely), no MFMA.
+// All are streaming kernels: 16-byte vector loads, fp32 statistics, no MFMA.  GroupNorm statistics
+// are one-pass SHIFTED sums (shift = the group's first element) or, when the producing GEMM / convolution
+// emitted column statistics in its epilogue, a merge of those (gn_stats_cols_kernel: no pass over the
+// tensor at all); LayerNorm is two-pass (mean, then centred variance) on a row held in registers.
 #include "common.cuh"
 
 namespace {
@@ -202,6 +204,52 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const void* x1, int C1
     const double var = fmax(Q / n - ms * ms, 0.0);
     stats[(int64_t)ig * 2 + 0] = sh + (float)ms;
     stats[(int64_t)ig * 2 + 1] = rsqrtf((float)var + eps);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------
+// GroupNorm statistics from epilogue column statistics (mimo_epilogue_ext.colstats of the producing GEMM /
+// convolution): cs[slab][0][c] = mean, cs[slab][1][c] = sum of squared deviations of the slab's 32 rows of column c.
+// One wave per (image, group) merges (slabs of the image) x (columns of the group) with Chan's parallel update
+// in double; lane-sequential, then a fixed xor butterfly: the result depends on the data only.
+// ---------------------------------------------------------------------------------
+struct Moments {
+  double n, mean, m2;
+};
+__device__ __forceinline__ Moments merge(const Moments& a, const Moments& b) {
+  if (b.n == 0.0) return a;
+  if (a.n == 0.0) return b;
+  const double n = a.n + b.n, d = b.mean - a.mean;
+  return Moments{n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n)};
+}
+
+__global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, int C1, const float* cs2, int C2,
+                                                            int64_t slabs_per_img, int groups, int total, float eps,
+                                                            float* stats) {
+  const int ig = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (ig >= total) return;
+  const int img = ig / groups, grp = ig % groups;
+  const int cpg = (C1 + C2) / groups, c0 = grp * cpg;
+  const int64_t items = slabs_per_img * cpg;
+  Moments acc{0.0, 0.0, 0.0};
+  for (int64_t i = lane; i < items; i += 64) {
+    const int64_t sl = img * slabs_per_img + i / cpg;
+    const int c = c0 + (int)(i % cpg);
+    const float* p = c < C1 ? cs1 + sl * 2 * C1 + c : cs2 + sl * 2 * C2 + (c - C1);
+    const int Cx = c < C1 ? C1 : C2;
+    acc = merge(acc, Moments{32.0, (double)p[0], (double)p[Cx]});
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Moments other{__shfl_xor(acc.n, o, 64), __shfl_xor(acc.mean, o, 64), __shfl_xor(acc.m2, o, 64)};
+    // both partners must compute the same value: merge in a canonical (lower lane first) order
+    acc = (lane & o) ? merge(other, acc) : merge(acc, other);
+  }
+  if (lane == 0) {
+    stats[(int64_t)ig * 2 + 0] = (float)acc.mean;
+    stats[(int64_t)ig * 2 + 1] = rsqrtf((float)(acc.m2 / acc.n) + eps);
   }
 }
 
@@ -440,6 +488,17 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
       hipLaunchKernelGGL(gn_finalize_kernel<MIMO_BF16>, dim3(fg), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, HW, groups, total, eps, partials, split, stats);
     MIMO_LAUNCH_CHECK();
   }
+  return MIMO_OK;
+}
+
+extern "C" int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
+                                          int groups, float eps, float* stats, void* stream) {
+  if (!cs1 || !stats || n <= 0 || HW <= 0 || (HW & 31) || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
+  if ((C1 + C2) % groups || (C2 > 0 && !cs2)) return MIMO_EINVAL;
+  const int total = n * groups;
+  hipLaunchKernelGGL(gn_stats_cols_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cs1, C1,
+                     cs2, C2, HW >> 5, groups, total, eps, stats);
+  MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }
 

@@ -8,10 +8,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
+# MIMO_HIP_LIB selects another build of the same sources (tools/microbench.py: libmimo_hip_tune.so, whose tuning knobs
+# are read from the environment); the default is the shipped library.
+LIB_PATH = os.environ.get("MIMO_HIP_LIB") or os.path.join(_HERE, "libmimo_hip.so")
 
 F16, BF16 = 0, 1
-EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32 = 1, 2, 4, 8
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, EPI_NO_SPLITK = 1, 2, 4, 8, 16
 
 c_vp, c_i, c_i64, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint
 c_sz = ctypes.c_size_t
@@ -23,6 +25,11 @@ class ConvParams(ctypes.Structure):
                                    "img_bias_ld")]
 
 
+class EpilogueExt(ctypes.Structure):  # mimo_epilogue_ext
+    _fields_ = [("colstats", c_vp), ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ln_pe", c_vp),
+                ("ln_eps", c_f), ("ln_pe_frames", c_i), ("ln_rows_per_frame", c_i64)]
+
+
 # name -> argtypes, mirrors include/mimo_hip.h one to one
 SIGNATURES = {
     "mimo_version": [],
@@ -30,7 +37,12 @@ SIGNATURES = {
     "mimo_workspace_bytes": [],
     "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp,
                   c_sz, c_vp],
+    "mimo_gemm_ext": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u,
+                      c_vp, c_sz, ctypes.POINTER(EpilogueExt), c_vp],
     "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz, c_vp],
+    "mimo_conv2d_ext": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz,
+                        ctypes.POINTER(EpilogueExt), c_vp],
+    "mimo_group_norm_stats_cols": [c_vp, c_i, c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
     "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp],

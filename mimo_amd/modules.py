@@ -47,6 +47,15 @@ class EarlyExit(Exception):
     pass
 
 
+_PACK_EPOCH = [0]
+
+
+def pack_epoch():
+    """Generation counter of the packed-weight caches: bumped whenever any HipModule drops its packed buffers.  Captured
+    hipGraphs hold those buffers by address and compare this before every replay (pipeline.GraphedDenoiser)."""
+    return _PACK_EPOCH[0]
+
+
 class HipModule(nn.Module):
     """Caches device-side packed weights per (dtype, device); invalidated by load_state_dict / _apply."""
 
@@ -54,6 +63,8 @@ class HipModule(nn.Module):
         key = (dtype, self._dev())
         cache = self.__dict__.setdefault("_pk", {})
         if key not in cache:
+            if cache:
+                _PACK_EPOCH[0] += 1  # another (dtype, device) replaces the buffers a captured graph may point at
             cache.clear()
             with torch.no_grad():
                 cache[key] = self._pack(dtype)
@@ -63,6 +74,7 @@ class HipModule(nn.Module):
         return next(self.parameters()).device
 
     def invalidate(self):
+        _PACK_EPOCH[0] += 1
         for m in self.modules():
             m.__dict__.pop("_pk", None)
 
@@ -112,12 +124,14 @@ class ResnetBlock(HipModule):
         if self.time_emb_proj is not None:
             s, e = self.temb_slice
             tb = ctx.temb[:, s:e]
+        # colstats=True: the conv epilogue also emits the GroupNorm column statistics of its output, so the norm
+        # that consumes it (norm2 here; the next block's norm for the block output) makes no statistics pass over HBM
         h = ops.conv2d(a1, p["w1"], self.out_channels, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
-                       out_f32=True)
+                       out_f32=True, colstats=True)
         a2, _ = ops.group_norm(h, p["g2"], p["be2"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
         return ops.conv2d(a2, p["w2"], self.out_channels, x2=raw, bias=p["b2"],
                           residual=None if fused_sc else x, out_f32=True,
-                          out_scale=1.0 / self.output_scale_factor)
+                          out_scale=1.0 / self.output_scale_factor, colstats=True)
 
 
 class Downsample(HipModule):
@@ -137,8 +151,8 @@ class Downsample(HipModule):
         n, H, W, _ = x.shape
         if self.padding == 0:
             return ops.conv2d(xh, p["w"], self.conv.out_channels, stride=2, pad=(0, 0),
-                              out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1), bias=p["b"], out_f32=True)
-        return ops.conv2d(xh, p["w"], self.conv.out_channels, stride=2, bias=p["b"], out_f32=True)
+                              out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1), bias=p["b"], out_f32=True, colstats=True)
+        return ops.conv2d(xh, p["w"], self.conv.out_channels, stride=2, bias=p["b"], out_f32=True, colstats=True)
 
 
 class Upsample(HipModule):
@@ -156,7 +170,7 @@ class Upsample(HipModule):
         _, xh = ops.group_norm(x, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
         n, H, W, _ = x.shape
         size = (2 * H, 2 * W) if output_size is None else tuple(output_size)
-        return ops.conv2d(xh, p["w"], self.conv.out_channels, upsample_to=size, bias=p["b"], out_f32=True)
+        return ops.conv2d(xh, p["w"], self.conv.out_channels, upsample_to=size, bias=p["b"], out_f32=True, colstats=True)
 
 
 class _Attn(nn.Module):
@@ -184,9 +198,8 @@ class _FeedForward(nn.Module):
         self.net = nn.ModuleList([_GEGLU(dim, 4 * dim), nn.Identity(), nn.Linear(4 * dim, dim)])
 
 
-def _ff_run(ctx, p, x_f32, norm_w, norm_b, out_f32):
-    """LN -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
-    n3 = ops.layer_norm(x_f32, norm_w, norm_b, dtype=ctx.dtype)
+def _ff_run(ctx, p, x_f32, n3, out_f32):
+    """(LN, already applied: n3) -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
     h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
     return ops.gemm(h, p["ff2_w"], bias=p["ff2_b"], residual=x_f32, out_f32=out_f32)
 
@@ -228,11 +241,18 @@ class SpatialTransformerBlock(HipModule):
         a2 = self.attn2
         return a2.to_out[0].weight.detach().float() @ a2.to_v.weight.detach().float(), _f32(a2.to_out[0].bias)
 
-    def run(self, ctx, t, n_img, N, out_f32=False):
-        """t: fp32 tokens [n_img*N, C].  Returns the block output (half unless out_f32)."""
+    def ln1(self, dtype):
+        """norm1 as the `ln=` argument of the GEMM that produces this block's input (fused into its epilogue)."""
+        p = self.packed(dtype)
+        return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps)
+
+    def run(self, ctx, t, n_img, N, out_f32=False, n1=None):
+        """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it.
+        Returns the block output (half unless out_f32)."""
         p = self.packed(ctx.dtype)
         C = self.dim
-        n1 = ops.layer_norm(t, p["n1w"], p["n1b"], dtype=ctx.dtype)
+        if n1 is None:
+            n1 = ops.layer_norm(t, p["n1w"], p["n1b"], eps=self.norm1.eps, dtype=ctx.dtype)
         if self.mode == "write":
             bank = n1.view(n_img, N, C)
             self.bank.append(bank if ctx.bank_rows is None else bank[ctx.bank_rows])
@@ -248,9 +268,11 @@ class SpatialTransformerBlock(HipModule):
         else:
             o = ops.attention(q, k, v, self.heads, q_prescaled=True)
         s, e = self.attn2_slice
-        y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
-                     rows_per_img=ctx.F * N, residual=t, out_f32=True)
-        return _ff_run(ctx, p, y, p["n3w"], p["n3b"], out_f32)
+        # to_out + collapsed attn2 + residual, with norm3 of the result fused into the same epilogue (C = 320)
+        y, n3 = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
+                         rows_per_img=ctx.F * N, residual=t, out_f32=True,
+                         ln=dict(gamma=p["n3w"], beta=p["n3b"], eps=self.norm3.eps))
+        return _ff_run(ctx, p, y, n3, out_f32)
 
     def set_bank(self, bank, dtype):
         """bank: half [1, Nb, C] (the cond reference features).  Projects K/V once (step- and frame-invariant)."""
@@ -288,10 +310,11 @@ class SpatialTransformer(HipModule):
         p = self.packed(ctx.dtype)
         n, H, W, C = x.shape
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=1e-6, silu=False, dtype=ctx.dtype)
-        t = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True)
-        z = self.transformer_blocks[0].run(ctx, t, n, H * W)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True)
-        return out.view(n, H, W, C)
+        blk = self.transformer_blocks[0]
+        t, n1 = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=blk.ln1(ctx.dtype))
+        z = blk.run(ctx, t, n, H * W, n1=n1)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=True)
+        return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
 
 
 class _TemporalAttn(nn.Module):
@@ -367,13 +390,14 @@ class MotionModule(HipModule):
         if ctx.F > self.max_len:
             raise ValueError(f"window of {ctx.F} frames exceeds temporal_position_encoding_max_len={self.max_len}")
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=32, eps=1e-6, silu=False, dtype=ctx.dtype)
-        t = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True)
+        # every LayerNorm (+ positional encoding) rides in the epilogue of the GEMM that produces its input
+        ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], pe=p[f"pe{i}"], rows_per_frame=HW, pe_frames=ctx.F) for i in range(2)]
+        ln.append(dict(gamma=p["fnw"], beta=p["fnb"]))
+        t, u = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=ln[0])
         for i in range(2):
-            u = ops.layer_norm(t, p[f"nw{i}"], p[f"nb{i}"], dtype=ctx.dtype, pe=p[f"pe{i}"], rows_per_frame=HW,
-                               pe_frames=ctx.F)
             qkv = ops.gemm(u, p[f"qkv{i}"])
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
-            t = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True)
-        z = _ff_run(ctx, p, t, p["fnw"], p["fnb"], out_f32=False)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True)
-        return out.view(n, H, W, C)
+            t, u = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True, ln=ln[i + 1])
+        z = _ff_run(ctx, p, t, u, out_f32=False)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=True)
+        return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))

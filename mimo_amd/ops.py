@@ -61,26 +61,73 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def set_split_k(enabled):
-    """Split-K changes the fp32 summation order of a long reduction as a function of the row count M, i.e. of the
-    batch size.  Runs that must be bit-identical across batch decompositions (one long clip sharded over ranks vs
-    the same clip on one GPU) switch it off on both sides; the default (on) is the faster single-GPU setting."""
-    import os
-    os.environ["MIMO_GEMM_SPLITK"] = "1" if enabled else "0"
-    L.call("mimo_reload_tuning")
+# Split-K changes the fp32 summation order of a long reduction as a function of the row count M, i.e. of the batch
+# size.  Runs that must be bit-identical across batch decompositions (one long clip sharded over ranks vs the same clip
+# on one GPU) switch it off: `with ops.split_k(False): ...` adds MIMO_EPI_NO_SPLITK to every gemm / conv2d call made
+# inside the block (a per-call flag of the C-ABI; the library itself keeps no state).
+_SPLIT_K = True
+
+
+class split_k:
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _SPLIT_K
+        self.saved, _SPLIT_K = _SPLIT_K, self.enabled
+        return self
+
+    def __exit__(self, *a):
+        global _SPLIT_K
+        _SPLIT_K = self.saved
+        return False
+
+
+def split_k_enabled():
+    return _SPLIT_K
 
 
 _WS = {}
 
 
 def _workspace(device):
-    """Split-K scratch handed to mimo_gemm / mimo_conv2d (include/mimo_hip.h, workspace convention): one fp32
-    buffer per (device, stream), reused by every launch (launches on one stream are ordered, so sharing is safe)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """Split-K scratch handed to mimo_gemm / mimo_conv2d (include/mimo_hip.h, workspace convention): ONE fp32 buffer
+    per device.  Only the split-K partial-sum launch pair of one call touches it, and the model issues its launches
+    on one stream at a time (during hipGraph capture: the capture stream), so stream order makes sharing safe."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(L.load().mimo_workspace_bytes() // 4, device=device, dtype=torch.float32)
     return ws
+
+
+# GroupNorm column statistics (mimo_epilogue_ext.colstats): a producer called with colstats=True attaches the
+# fp32 [M/32, 2, N] tensor to its output as `_cs`; group_norm() consumes it instead of re-reading the tensor.
+# Rows M below this keep split-K available instead (the 8x8 level, where one more pass over 16 MB is cheaper).
+COLSTATS_MIN_ROWS = 8192
+
+
+def with_stats(t, cs):
+    """Re-attach column statistics after a view (views are new tensor objects)."""
+    if cs is not None:
+        t._cs = cs
+    return t
+
+
+def stats_of(t):
+    return getattr(t, "_cs", None)
+
+
+def _ext(colstats=None, ln_out=None, ln=None):
+    e = L.EpilogueExt()
+    e.colstats = _ptr(colstats)
+    e.ln_out = _ptr(ln_out)
+    if ln is not None:
+        e.ln_gamma, e.ln_beta, e.ln_pe = ln["gamma"].data_ptr(), ln["beta"].data_ptr(), _ptr(ln.get("pe"))
+        e.ln_eps = float(ln.get("eps", 1e-5))
+        e.ln_pe_frames = int(ln.get("pe_frames", 0) or 0)
+        e.ln_rows_per_frame = int(ln.get("rows_per_frame", 0) or 0)
+    return e
 
 
 def _chk(t, name):
@@ -97,8 +144,12 @@ def _is_f32(t):
 
 
 def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f32=False, silu=False,
-         geglu=False, out=None, out_scale=1.0):
-    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1)."""
+         geglu=False, out=None, out_scale=1.0, colstats=False, ln=None):
+    """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1).
+
+    colstats=True: also emit GroupNorm column statistics of `out` (attached as out._cs) when the shape allows.
+    ln=dict(gamma, beta[, eps, pe, rows_per_frame, pe_frames]): also return LayerNorm(out) (+ pe) as a half tensor —
+    fused into the epilogue when N == 320, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out)."""
     _chk(a, "a")
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
     assert a.dtype == w.dtype
@@ -120,17 +171,39 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     if img_bias is not None:
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
         ldib = img_bias.stride(0)
+    if not _SPLIT_K:
+        flags |= L.EPI_NO_SPLITK
+    fuse_ln = (ln is not None and N == 320 and not geglu and not silu and out.stride(0) == N and out.is_contiguous()
+               and (residual is None or ldr == N)
+               and (ln.get("pe") is None or (ln.get("rows_per_frame", 0) % 128 == 0 and ln.get("pe_frames", 0) > 0)))
+    cs = ln_out = None
+    if colstats and not fuse_ln and not geglu and M % 32 == 0 and M >= COLSTATS_MIN_ROWS and N % 4 == 0:
+        cs = torch.empty((M // 32, 2, N), device=a.device, dtype=torch.float32)
+    if fuse_ln:
+        ln_out = torch.empty((M, N), device=a.device, dtype=a.dtype)
     _count(2 * M * N * K)
     with _Bracket("gemm_kernel", 2 * M * N * K):
         ws = _workspace(a.device)
-        L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
-               out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
-               float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, _stream())
-    return out
+        if cs is None and ln_out is None:
+            L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
+                   out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
+                   float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, _stream())
+        else:
+            ext = _ext(colstats=cs, ln_out=ln_out, ln=ln if fuse_ln else None)
+            L.call("mimo_gemm_ext", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
+                   out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
+                   float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, ctypes.byref(ext), _stream())
+    with_stats(out, cs)
+    if ln is None:
+        return out
+    if ln_out is None:
+        ln_out = layer_norm(out, ln["gamma"], ln["beta"], eps=ln.get("eps", 1e-5), dtype=a.dtype, pe=ln.get("pe"),
+                            rows_per_frame=ln.get("rows_per_frame", 0), pe_frames=ln.get("pe_frames", 0))
+    return out, ln_out
 
 
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
-           img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0):
+           img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0, colstats=False):
     """Channels-last implicit-GEMM conv.  x: half [n, H, W, Cin]; w: packed half [cout, ks*ks*Cin (+Cin2)].
 
     pad = (pad_top, pad_left); default (ks//2, ks//2).  out_hw defaults to the torch formula for
@@ -162,14 +235,26 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == out.shape
         flags |= L.EPI_RES_F32 if residual.dtype == torch.float32 else 0
+    if not _SPLIT_K:
+        flags |= L.EPI_NO_SPLITK
+    M = n * Ho * Wo
+    cs = None
+    if colstats and M % 32 == 0 and (Ho * Wo) % 32 == 0 and M >= COLSTATS_MIN_ROWS and cout % 4 == 0:
+        cs = torch.empty((M // 32, 2, cout), device=x.device, dtype=torch.float32)
     fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
     _count(fl)
     with _Bracket("gemm_kernel", fl):
         ws = _workspace(x.device)
-        L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
-               ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags,
-               ws.data_ptr(), ws.numel() * 4, _stream())
-    return out
+        if cs is None:
+            L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
+                   ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags,
+                   ws.data_ptr(), ws.numel() * 4, _stream())
+        else:
+            ext = _ext(colstats=cs)
+            L.call("mimo_conv2d_ext", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
+                   ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), float(out_scale), flags,
+                   ws.data_ptr(), ws.numel() * 4, ctypes.byref(ext), _stream())
+    return with_stats(out, cs)
 
 
 def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dtype=None, want_raw=False,
@@ -190,7 +275,15 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
         assert _is_f32(x2) == f32 and x2.numel() // (n * C2) == HW
     shape = tuple(x1.shape[:-1]) + (C1 + C2,)
     out = raw = stats = None
-    if want_norm:
+    cs1, cs2 = stats_of(x1), (None if x2 is None else stats_of(x2))
+    if want_norm and cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 \
+            and cs1.shape[0] * 32 == n * HW and (cs2 is None or cs2.shape[0] == cs1.shape[0]):
+        # the producers' epilogues already reduced every 32-row slab: merge slabs x group columns, no pass over x
+        stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
+        L.call("mimo_group_norm_stats_cols", cs1.data_ptr(), C1, _ptr(cs2), C2, n, HW, groups, float(eps),
+               stats.data_ptr(), _stream())
+        out = torch.empty(shape, device=x1.device, dtype=dtype)
+    elif want_norm:
         stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
         C = C1 + C2
         if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):

@@ -7,9 +7,12 @@ CLIP embedding + VAE encode (ref + F background frames) + pose guider + referenc
 + {sliding windows x CFG -> denoising UNet -> window average -> guidance -> DDIM} x steps + VAE decode.
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): the independent work units of a step are
-(context window, CFG half) pairs; they are dealt round-robin to the ranks, each rank runs its units as
-b=1 denoising forwards, the per-unit predictions are exchanged with ONE all_gather per step and every rank
-replays the window sum in canonical order, so the result is bit-identical to the single-GPU run.
+(context window, CFG half) pairs; they are dealt to the ranks heaviest first in a snake (the cond half attends
+twice the keys), each rank runs its units as b=1 denoising forwards, and the per-unit predictions travel in
+pre-allocated slot buffers: slot k of every rank is all-gathered (async, RCCL's own stream) as soon as the
+rank's k-th unit is done, i.e. under the compute of unit k+1; only the last slot's gather is exposed.  Every rank
+then replays the window sum in canonical order, so the result is bit-identical to the single-GPU run.
+Ranks without a unit (world > units) take part with zero slots.
 """
 import math
 
@@ -41,10 +44,24 @@ def preprocess_image(image, height, width, normalize, scale_factor=8):
 
 def plan_units(num_windows, cfg, rank, world):
     """Work decomposition of one denoising step.  Units = (window, half) in canonical order
-    (w0/uncond, w0/cond, w1/uncond, ...); unit u belongs to rank u % world.  Returns (all_units, my_units)."""
+    (w0/uncond, w0/cond, w1/uncond, ...).  Assignment: cond halves (two KV segments: the heavier unit) first, then
+    uncond halves, dealt over the ranks in a snake (0..world-1, world-1..0, ...) so that every rank gets the same
+    number of units +-1 and heavy / light units alternate per rank.  Returns (all_units, my_units in slot order)."""
     halves = (0, 1) if cfg else (0,)
     units = [(w, h) for w in range(num_windows) for h in halves]
-    return units, [u for i, u in enumerate(units) if i % world == rank]
+    return units, [u for u, r, _ in assign_units(units, world) if r == rank]
+
+
+def assign_units(units, world):
+    """[(unit, rank, slot)]: the snake deal of plan_units; slot = the unit's index among its rank's units."""
+    order = sorted(units, key=lambda u: (-u[1], u[0]))  # cond (half 1) first, window order inside
+    out, nslot = [], [0] * world
+    for k, u in enumerate(order):
+        rnd, pos = divmod(k, world)
+        r = pos if rnd % 2 == 0 else world - 1 - pos
+        out.append((u, r, nslot[r]))
+        nslot[r] += 1
+    return out
 
 
 def _all_gather(send, world, group=None):
@@ -65,7 +82,6 @@ def sharded_frames(fn, x, rank, world, group=None):
     """Per-frame stage (VAE encode / decode, pose guider) over frames [F, ...] with the frames dealt in contiguous
     chunks over the ranks: every rank runs `fn` on its chunk only, one all_gather rebuilds the full result on every
     rank.  Per-frame ops are independent of the batch they run in, so the result equals the unsharded call."""
-    import torch.distributed as dist
     F = x.shape[0]
     per = math.ceil(F / world)
     lo, hi = min(F, rank * per), min(F, (rank + 1) * per)
@@ -77,21 +93,71 @@ def sharded_frames(fn, x, rank, world, group=None):
     return torch.cat(_all_gather(send, world, group), 0)[:F].contiguous()
 
 
-def exchange_predictions(my_preds, units, rank, world, group=None):
-    """all_gather of the per-unit prediction tensors (equal shapes).  Returns {unit: tensor} for ALL units.
-    Ranks own ceil/floor(len(units)/world) units; short ranks pad with a zero tensor."""
-    import torch.distributed as dist
-    per_rank = math.ceil(len(units) / world)
-    proto = next(iter(my_preds.values())) if my_preds else None
-    if proto is None:  # a rank with no unit still needs the shape: broadcast it from rank 0's first unit
-        raise RuntimeError("every rank must own at least one unit (world size > number of units)")
-    mine = [u for i, u in enumerate(units) if i % world == rank]
-    send = torch.stack([my_preds[u] for u in mine] + [torch.zeros_like(proto)] * (per_rank - len(mine)))
-    recv = _all_gather(send, world, group)
-    out = {}
-    for i, u in enumerate(units):
-        out[u] = recv[i % world][i // world]
-    return out
+class UnitExchange:
+    """Pre-allocated exchange of per-unit predictions (fp32 [Fw, h, w, C] each).
+
+    Rank r owns ceil/floor(len(units)/world) slots.  `put(slot, pred)` copies the prediction into the rank's send
+    slot and immediately starts the all-gather of THAT slot index over all ranks (async_op: RCCL runs it on its own
+    stream, ordered after the producing kernels by an event), so the gather of slot k overlaps the compute of the
+    rank's unit k+1.  `finish()` starts the gathers of slots this rank does not fill (it sends zeros there), waits
+    for all of them and returns {unit: tensor}.  Buffers are allocated once per (shape, world) and reused every step."""
+
+    def __init__(self, units, rank, world, shape, device, group=None):
+        self.units, self.rank, self.world, self.group = units, rank, world, group
+        self.assign = assign_units(units, world)
+        self.nslots = math.ceil(len(units) / world) if units else 0
+        self.send = torch.zeros((self.nslots,) + tuple(shape), device=device, dtype=torch.float32)
+        self.recv = torch.zeros((self.nslots, world) + tuple(shape), device=device, dtype=torch.float32)
+        self.my_slots = sum(1 for _, r, _ in self.assign if r == rank)
+        self._host = None
+        self.begin()
+
+    def begin(self):
+        self.works, self.started = [], 0
+
+    def _gather_slot(self, k):
+        import torch.distributed as dist
+        if self.send.is_cuda and dist.get_backend(self.group) == "gloo":  # no device collectives in gloo: host staging
+            host = self.send[k].reshape(-1).cpu()
+            out = torch.empty((self.world * host.numel(),), dtype=host.dtype)
+            dist.all_gather_into_tensor(out, host, group=self.group)
+            self.recv[k].copy_(out.view(self.recv[k].shape))
+            return
+        # flat views: the concatenated form of all_gather_into_tensor is accepted by every backend
+        self.works.append(dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), group=self.group,
+                                                      async_op=True))
+
+    def put(self, pred):
+        k = self.started
+        self.send[k].copy_(pred)
+        self._gather_slot(k)
+        self.started += 1
+
+    def finish(self):
+        while self.started < self.nslots:  # slots this rank has no unit for carry zeros
+            self.send[self.started].zero_()
+            self._gather_slot(self.started)
+            self.started += 1
+        for w in self.works:
+            w.wait()
+        out = {u: self.recv[slot, r] for u, r, slot in self.assign}
+        self.begin()
+        return out
+
+
+def exchange_predictions(my_preds, units, rank, world, group=None, shape=None, device=None):
+    """One-shot form of UnitExchange: {unit: tensor} of this rank's units -> {unit: tensor} for ALL units.  A rank that
+    owns no unit (world > len(units)) must pass `shape` / `device` (known on the host: [Fw, h, w, C] fp32)."""
+    if my_preds:
+        proto = next(iter(my_preds.values()))
+        shape, device = tuple(proto.shape), proto.device
+    elif shape is None:
+        raise ValueError("a rank without units must be given the unit shape")
+    ex = UnitExchange(units, rank, world, shape, device or "cpu", group)
+    for u, r, _ in ex.assign:  # slot order of this rank
+        if r == rank:
+            ex.put(my_preds[u])
+    return ex.finish()
 
 
 class GraphedDenoiser:
@@ -121,13 +187,25 @@ class GraphedDenoiser:
             self.out = self.unet.run_tokens(self.x, self.t, self.ehs, self.b, self.F, self.pose)
         self.work, ops.COUNTER = ops.COUNTER, saved  # algorithmic FLOPs / launches replayed by every graph launch
 
+    def fingerprint(self):
+        """Everything a captured graph bakes in by ADDRESS or by VALUE besides the static input buffers: the bank K/V
+        buffers of the spatial blocks, the packed-weight generation (HipModule.invalidate drops packed buffers on
+        .to() / load_state_dict) and the split-K setting.  A replay with a different fingerprint would read freed or
+        stale memory, so the graph is re-captured instead."""
+        from .modules import pack_epoch
+        banks = tuple(0 if b.bank_kv is None else b.bank_kv.data_ptr() for b in self.unet.spatial_blocks())
+        return (banks, pack_epoch(), ops.split_k_enabled())
+
     def __call__(self, x, t, ehs, pose):
         self.x.copy_(x)
         self.pose.copy_(pose)
         self.t.fill_(float(t))
         self.ehs.copy_(ehs)
+        if self.graph is not None and self.fp != self.fingerprint():
+            self.graph = None  # stale addresses: drop and re-capture
         if self.graph is None:
             self.capture()
+            self.fp = self.fingerprint()
         self.graph.replay()
         if ops.COUNTER is not None:
             ops.COUNTER["flops"] += self.work["flops"]
@@ -189,11 +267,20 @@ class Pose2VideoPipeline:
         return torch.cat(frames).permute(1, 0, 2, 3)[None]
 
     @torch.no_grad()
-    def run_tensors(self, ref_image, bk_images, pose_images, clip_embeds, latents, num_inference_steps,
-                    guidance_scale, context_schedule="uniform", context_frames=24, context_stride=1,
-                    context_overlap=4, callback=None, return_latents=False, decode=True, trajectory=None):
+    def run_tensors(self, *args, **kwargs):
         """Device-resident core.  ref_image [1,3,H,W] in [-1,1]; bk_images [F,3,H,W] in [-1,1]; pose_images
-        [F,3,H,W] in [0,1]; clip_embeds [1,768]; latents fp32 [1,4,F,h,w] (the injected initial noise)."""
+        [F,3,H,W] in [0,1]; clip_embeds [1,768]; latents fp32 [1,4,F,h,w] (the injected initial noise).
+        (Signature: see _run_tensors.)  Split-K is a per-call flag of the C-ABI: it is switched off for THIS run only
+        when the summation order must not depend on how the clip is cut into batches."""
+        world = 1
+        if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(self.dist_group)
+        with ops.split_k(not (world > 1 or self.batch_invariant)):
+            return self._run_tensors(*args, **kwargs)
+
+    def _run_tensors(self, ref_image, bk_images, pose_images, clip_embeds, latents, num_inference_steps,
+                     guidance_scale, context_schedule="uniform", context_frames=24, context_stride=1,
+                     context_overlap=4, callback=None, return_latents=False, decode=True, trajectory=None):
         dev = self.device
         unet, sched = self.denoising_unet, self.scheduler
         dt = unet.compute_dtype
@@ -202,8 +289,6 @@ class Pose2VideoPipeline:
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             import torch.distributed as dist
             rank, world = dist.get_rank(self.dist_group), dist.get_world_size(self.dist_group)
-        if world > 1 or self.batch_invariant:
-            ops.set_split_k(False)  # summation order must not depend on how the clip is cut into batches
         sched.set_timesteps(num_inference_steps)
         latents = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
         _, C, F, h, w = latents.shape
@@ -257,6 +342,10 @@ class Pose2VideoPipeline:
         win_bk = [bk_tok[c.long()] for c in win_idx]
         win_pose = [pose_tok[c.long()] for c in win_idx]
         units, my_units = plan_units(len(windows), cfg, rank, world)
+        exch = None
+        if world > 1:  # every window has the same frame count; the UNet's output head is padded to 4 channels
+            cpad = (unet.out_channels + 3) // 4 * 4
+            exch = UnitExchange(units, rank, world, (len(windows[0]), h, w, cpad), dev, self.dist_group)
         acc = torch.empty((2 if cfg else 1, C, F, h, w), device=dev, dtype=torch.float32)
         counter = torch.empty((F,), device=dev, dtype=torch.float32)
 
@@ -284,8 +373,9 @@ class Pose2VideoPipeline:
                     lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
                     x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
                     e = ehs[half:half + 1] if cfg else ehs
-                    preds[(wi, half)] = self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg))
-                allp = exchange_predictions(preds, units, rank, world, self.dist_group)
+                    # the gather of this unit's slot starts now and runs under the next unit's forward
+                    exch.put(self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg)))
+                allp = exch.finish()
                 for wi, idx in enumerate(win_idx):
                     halves = [allp[(wi, hf)] for hf in ((0, 1) if cfg else (0,))]
                     ops.window_accumulate(torch.cat(halves, 0).contiguous(), idx, acc, counter)

@@ -220,7 +220,7 @@ class UNetBase(HipModule):
         n, H, W, _ = x_tok.shape
         up = 2 ** self.num_upsamplers
         forward_upsample_size = (H % up != 0) or (W % up != 0)
-        x = ops.conv2d(x_tok, p["ci_w"], self.boc[0], bias=p["ci_b"], residual=pose_tok, out_f32=True)
+        x = ops.conv2d(x_tok, p["ci_w"], self.boc[0], bias=p["ci_b"], residual=pose_tok, out_f32=True, colstats=True)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk.run(ctx, x)

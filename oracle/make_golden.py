@@ -2,13 +2,17 @@
 (/root/reference/src behind oracle/diffusers_standin.py, CPU fp32) on seeded synthetic weights and inputs.
 Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, same torch CPU generator).
 
-    python -m oracle.make_golden [small] [forward512] [config1] [config2]
+    python -m oracle.make_golden [small] [forward512] [config1] [config2] [config2_video] [multiwindow]
 
   small       half-width UNets (4 heads, d = 40/80/160): denoising forward + banks, odd-size forward
   forward512  FULL-SIZE denoising UNet, config-2 shapes: one forward on 2 x 24 latent frames 64x64 (about 4 min, 15 GB)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
   config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
               0, 9, 19; about 70 min and 19 GB on 8 cores)
+  config2_video  decoded frames 0 and 23 of config2's final latents (oracle VAE decode of the stored reference latents)
+  multiwindow FULL-SIZE models through the reference's OWN Pose2VideoPipeline.__call__ (PIL in, .videos out):
+              512x512, F = 48 -> three 24-frame context windows (the last wraps to frame 0), 4 DDIM steps, CFG 3.5;
+              latents after steps 0 and 3 (callback), decoded frames 0 and 47 (about 40 min and 25 GB on 8 cores)
 """
 import os
 import sys
@@ -155,9 +159,87 @@ def _clip(size, F, steps, keep, fname, keep_pose=True):
     save_file(traj, os.path.join(OUT, fname))
 
 
+def config2_video():
+    """Decoded video frames for the config-2 fixture: the oracle VAE (diffusers AutoencoderKL restatement, seed 1237)
+    applied to the reference's final latents as decode_latents does (pipeline :113-126)."""
+    from safetensors.torch import load_file
+    G = load_file(os.path.join(OUT, "config2_512_24f_20steps.safetensors"))
+    vae = synth.build(OP.AutoencoderKL, 1237)
+    lat = G["latents_step19"] / 0.18215
+    out = {}
+    with torch.no_grad():
+        for f in (0, 23):
+            img = vae.decode(lat[:, :, f]).sample
+            out[f"video_frame{f}"] = (img / 2 + 0.5).clamp(0, 1)[0]
+    save_file(out, os.path.join(OUT, "config2_512_24f_video_frames.safetensors"))
+    print("config2_video:", {k: tuple(v.shape) for k, v in out.items()})
+
+
+MW = dict(size=512, F=48, steps=4, guidance=3.5, seed=42)
+
+
+def multiwindow_inputs(size, F):
+    """Synthetic PIL inputs of the multi-window fixture (regenerated by the test, not stored)."""
+    import numpy as np
+    from PIL import Image
+    mk = lambda s: Image.fromarray(np.random.RandomState(s).randint(0, 256, (size, size, 3), dtype=np.uint8))
+    return mk(0), [mk(100 + i) for i in range(F)], [mk(200 + i) for i in range(F)]
+
+
+def clip_embedding():
+    return torch.randn(1, 768, generator=torch.Generator().manual_seed(3))
+
+
+class FakeClip(torch.nn.Module):
+    """image_encoder stub: a fixed seeded embedding (the CLIP tower is pinned separately against transformers)."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.emb = clip_embedding()
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def forward(self, x):
+        return type("O", (), {"image_embeds": self.emb.to(x.device)})()
+
+
+def multiwindow():
+    from src.pipelines.pipeline_pose2vid_long_edit_bkfill_roiclip import Pose2VideoPipeline
+    import src.models.pose_guider as pg
+    size, F, steps = MW["size"], MW["F"], MW["steps"]
+    t0 = time.time()
+    r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, size // 8, 1234, 1235)
+    opg = synth.build(OM.PoseGuider, 1236)
+    rpg = pg.PoseGuider(320, 3, (16, 32, 96, 256)).eval()
+    rpg.load_state_dict(opg.state_dict())
+    vae = synth.build(OP.AutoencoderKL, 1237)
+    sched = OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
+    pipe = Pose2VideoPipeline(vae=vae, image_encoder=FakeClip(), reference_unet=r2, denoising_unet=r3, pose_guider=rpg,
+                              scheduler=sched)
+    print(f"models built in {time.time()-t0:.0f} s", flush=True)
+    ref_img, poses, bks = multiwindow_inputs(size, F)
+    traj = []
+
+    def cb(i, t, lat):  # the reference passes the shadowed window-batch index as i (:505); count calls instead
+        traj.append(lat.detach().clone())
+        print("step", len(traj) - 1, int(t), time.strftime("%H:%M:%S"), flush=True)
+
+    video = pipe(ref_img, poses, bks, size, size, F, steps, MW["guidance"], generator=torch.manual_seed(MW["seed"]),
+                 callback=cb, callback_steps=1).videos
+    assert len(traj) == steps and video.shape == (1, 3, F, size, size)
+    out = {"latents_step0": traj[0], f"latents_step{steps-1}": traj[-1],
+           "video_frame0": video[0, :, 0], f"video_frame{F-1}": video[0, :, F - 1]}
+    save_file(out, os.path.join(OUT, "multiwindow_512_48f_4steps.safetensors"))
+    print(f"multiwindow done in {time.time()-t0:.0f} s", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     install()
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ["small"]
     for w in what:
-        {"small": small, "forward512": forward512, "config1": config1, "config2": config2}[w]()
+        {"small": small, "forward512": forward512, "config1": config1, "config2": config2,
+         "config2_video": config2_video, "multiwindow": multiwindow}[w]()

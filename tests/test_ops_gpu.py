@@ -178,13 +178,9 @@ def test_split_k_long_reduction_few_tiles(dev, dtype):
         o3 = ops.gemm(a4, w4, bias=b, residual=res.view(-1, cout).to(dtype))
         return o1, o2, o3, a4, w4
 
-    try:
-        os.environ["MIMO_GEMM_SPLITK"] = "0"
-        L.call("mimo_reload_tuning")
+    with ops.split_k(False):  # MIMO_EPI_NO_SPLITK on every call inside: the unsplit reference
         u1, u2, u3, a4, w4 = run()
-    finally:
-        os.environ.pop("MIMO_GEMM_SPLITK", None)
-        L.call("mimo_reload_tuning")
+    assert ops.split_k_enabled()
     s1, s2, s3, _, _ = run()
     assert rel_l2(s1, ref) < ACC_TOL and rel_l2(s1, u1) < 1e-5
     assert rel_l2(s2.float(), u2.float()) < OUT_TOL[dtype]
@@ -245,6 +241,75 @@ def test_layer_norm_and_pe(dev, dtype, C):
     assert rel_l2(out.float(), ref + pe[fidx]) < OUT_TOL[dtype]
 
 
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw,C1,C2", [(32, 320, 0), (32, 640, 320), (16, 1280, 640), (64, 320, 320)])
+def test_group_norm_from_epilogue_column_stats(dev, dtype, hw, C1, C2):
+    """GroupNorm statistics merged from the column statistics that the PRODUCING conv / GEMM epilogue emitted
+    (mimo_epilogue_ext.colstats -> mimo_group_norm_stats_cols) equal a pass over the tensor.  The virtual concat puts
+    group boundaries inside a tensor's column range (C1 = 1280, C2 = 640: 60 channels per group)."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv
+    n = max(9, -(-8192 // (hw * hw)))  # M = n * hw * hw >= 8192 rows: the fused-statistics path
+    a = rnd((n, hw, hw, 64), dev, dtype, 1)
+    res = rnd((n, hw, hw, C1), dev, torch.float32, 5) * 2 + 0.7
+    w1 = pack_conv(rnd((C1, 64, 3, 3), dev, torch.float32, 2) * 0.05, dtype)
+    b1 = rnd((C1,), dev, torch.float32, 3)
+    x1 = ops.conv2d(a, w1, C1, bias=b1, residual=res, out_f32=True, colstats=True)
+    assert ops.stats_of(x1) is not None and ops.stats_of(x1).shape == (n * hw * hw // 32, 2, C1)
+    x2 = None
+    if C2:  # the second tensor comes from a dense GEMM (the proj_out / motion-module producers)
+        wl = rnd((C2, 64), dev, dtype, 6, 0.2)
+        x2f = ops.gemm(a.view(-1, 64), wl, bias=rnd((C2,), dev, torch.float32, 7), out_f32=True, colstats=True)
+        assert ops.stats_of(x2f) is not None
+        x2 = ops.with_stats(x2f.view(n, hw, hw, C2), ops.stats_of(x2f))
+    C = C1 + C2
+    gamma = rnd((C,), dev, torch.float32, 8) * 0.1 + 1
+    beta = rnd((C,), dev, torch.float32, 9) * 0.1
+    fused, _ = ops.group_norm(x1, gamma, beta, eps=1e-5, silu=True, x2=x2, dtype=dtype)
+    plain, _ = ops.group_norm(x1.clone(), gamma, beta, eps=1e-5, silu=True, x2=None if x2 is None else x2.clone(), dtype=dtype)
+    cat = torch.cat([x1, x2], dim=-1) if C2 else x1
+    ref = F.silu(F.group_norm(cat.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5).permute(0, 2, 3, 1))
+    assert rel_l2(fused.float(), ref) < OUT_TOL[dtype]
+    assert rel_l2(fused.float(), plain.float()) < OUT_TOL[dtype]
+    # the statistics epilogue stores exactly what the ordinary epilogue stores
+    x1b = ops.conv2d(a, w1, C1, bias=b1, residual=res, out_f32=True)
+    assert torch.equal(x1, x1b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,with_res,with_pe", [(4096, 320, True, True), (1000, 320, True, False), (8192, 1280, False, True), (130, 64, True, False)])
+def test_gemm_fused_layer_norm_output(dev, dtype, M, K, with_res, with_pe):
+    """LayerNorm (+ positional table) of the GEMM result, produced in the same epilogue as a second (half) output at
+    N = 320: the nn.LayerNorm that follows proj_in / to_out / the motion-module attention outputs."""
+    from mimo_amd import ops
+    N, HW, Fr = 320, 128, 4
+    a = rnd((M, K), dev, dtype, 1)
+    w = rnd((N, K), dev, dtype, 2, K ** -0.5)
+    b = rnd((N,), dev, torch.float32, 3)
+    res = rnd((M, N), dev, torch.float32, 4) * 1.5 + 0.2 if with_res else None
+    g = rnd((N,), dev, torch.float32, 5) * 0.1 + 1
+    be = rnd((N,), dev, torch.float32, 6) * 0.1
+    pe = rnd((32, N), dev, torch.float32, 7) if with_pe else None
+    ln = dict(gamma=g, beta=be, eps=1e-5)
+    if with_pe:
+        ln.update(pe=pe, rows_per_frame=HW, pe_frames=Fr)
+    out, y = ops.gemm(a, w, bias=b, residual=res, out_f32=True, ln=ln)
+    ref_out = a.float() @ w.float().t() + b + (res if with_res else 0)
+    assert rel_l2(out, ref_out) < ACC_TOL
+    ref_y = F.layer_norm(ref_out, (N,), g, be, 1e-5)
+    if with_pe:
+        ref_y = ref_y + pe[(torch.arange(M, device=dev) // HW) % Fr]
+    assert y.dtype == dtype and rel_l2(y.float(), ref_y) < OUT_TOL[dtype]
+    # same fp32 output as the call without the fused LayerNorm
+    assert rel_l2(out, ops.gemm(a, w, bias=b, residual=res, out_f32=True)) < 1e-6
+    # other widths fall back to mimo_layer_norm behind the same interface
+    w2 = rnd((640, K), dev, dtype, 8, K ** -0.5)
+    g2, be2 = rnd((640,), dev, torch.float32, 9) * 0.1 + 1, rnd((640,), dev, torch.float32, 10) * 0.1
+    o2, y2 = ops.gemm(a, w2, out_f32=True, ln=dict(gamma=g2, beta=be2))
+    assert rel_l2(y2.float(), F.layer_norm(a.float() @ w2.float().t(), (640,), g2, be2, 1e-5)) < OUT_TOL[dtype]
+
+
 def sdpa_ref(q, k, v, heads):
     B, Nq, C = q.shape
     d = C // heads
@@ -294,6 +359,7 @@ def test_attention_forced_rescale(dev, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("d,N,Nb,spike", [(40, 256, 256, 0), (40, 130, 70, 0), (40, 192, 0, 4), (40, 200, 64, 4), (40, 192, 0, 40),
+                                          (40, 600, 300, 4), (40, 1024, 1024, 0), (40, 64, 0, 0), (40, 1, 3, 0),
                                           (80, 100, 100, 0), (160, 64, 0, 4)])
 def test_attention_prescaled_q(dev, dtype, d, N, Nb, spike):
     """q already carries softmax_scale * log2(e) (folded into W_q): C-ABI scale <= 0.  d = 40 runs the variant that

@@ -13,7 +13,7 @@ from mimo_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 dt = torch.float16
-ops.set_split_k(False)
+ops.split_k(False).__enter__()  # MIMO_EPI_NO_SPLITK on every call of this script
 _, _, p3, p2 = build_pair_unets(dt, dev, seed=61)
 _, pv = build_pair_vae(dt, dev, seed=62)
 _, pg = build_pair_pose(dt, dev, seed=63)

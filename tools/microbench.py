@@ -6,7 +6,11 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the tuning knobs exist only in the -DMIMO_TUNE build of the library (python -m mimo_amd.build --tune)
+if "--ab" in sys.argv or "--attn-ab" in sys.argv or os.environ.get("MIMO_USE_TUNE_LIB"):
+    os.environ.setdefault("MIMO_HIP_LIB", os.path.join(ROOT, "mimo_amd", "libmimo_hip_tune.so"))
 from mimo_amd import lib as L, ops  # noqa: E402
 from mimo_amd.packing import pack_conv, pack_geglu  # noqa: E402
 
@@ -72,6 +76,75 @@ def ab_table(settings, dt, dev, n):
     L.call("mimo_reload_tuning")
 
 
+def med_interleaved(fns, rounds=5, iters=10):
+    """Interleaved timing of several variants of one case: `rounds` rounds, each variant timed in turn; min and median."""
+    ts = [[] for _ in fns]
+    for _ in range(rounds):
+        for i, fn in enumerate(fns):
+            ts[i].append(timeit(fn, iters=iters, warm=2))
+    return [(min(t), sorted(t)[len(t) // 2]) for t in ts]
+
+
+def attn_ab(dt, dev):
+    """Spatial attention d = 40: legacy kernel vs attn40_kernel program orders (tune build: MIMO_ATTN40_* knobs)."""
+    variants = [("legacy", {"MIMO_ATTN40_LEGACY": "1"}), ("v2 order0", {"MIMO_ATTN40_ORDER": "0"}),
+                ("v2 order1", {"MIMO_ATTN40_ORDER": "1"}), ("v2 order2", {"MIMO_ATTN40_ORDER": "2"})]
+    for (N, C, nb) in [(4096, 320, 48), (1024, 320, 48), (9604, 320, 8)]:
+        qkv = torch.randn(nb, N, 3 * C, device=dev).to(dt)
+        bank = torch.randn(N, 2 * C, device=dev).to(dt)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        fl = 4 * N * C * ((nb // 2) * N + (nb // 2) * 2 * N)
+
+        def mk(env):
+            def f():
+                for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_ORDER"):
+                    os.environ.pop(kk, None)
+                os.environ.update(env)
+                return ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=nb // 2, q_prescaled=True)
+            return f
+        fns = [mk(env) for _, env in variants]
+        outs = [f().float() for f in fns]
+        res = med_interleaved(fns)
+        for (name, _), (tmin, tmed), o in zip(variants, res, outs):
+            err = float((o - outs[0]).norm() / outs[0].norm())
+            print(f"attn N{N} d40 b{nb} {name:10s}: min {tmin*1e3:7.3f} ms med {tmed*1e3:7.3f} ms  {fl/tmin/1e12:7.1f} TF/s  rel-L2 vs legacy {err:.1e}", flush=True)
+    for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_ORDER"):
+        os.environ.pop(kk, None)
+
+
+def fused_paths(dt, dev):
+    """Round-2 fusions against the launches they replace: epilogue column statistics vs the GroupNorm statistics pass,
+    LayerNorm in the GEMM epilogue vs GEMM + mimo_layer_norm."""
+    n = 48
+    for (hw, C) in [(64, 320), (32, 640), (16, 1280)]:
+        x = torch.randn(n, hw, hw, C, device=dev).to(dt)
+        w = pack_conv(torch.randn(C, C, 3, 3, device=dev) * 0.02, dt)
+        b = torch.zeros(C, device=dev)
+        g = torch.ones(C, device=dev)
+        plain = lambda: ops.conv2d(x, w, C, bias=b, out_f32=True)
+        stats = lambda: ops.conv2d(x, w, C, bias=b, out_f32=True, colstats=True)
+        y = stats()
+        y0 = plain()
+        gn_cols = lambda: ops.group_norm(y, g, b, silu=True, dtype=dt)
+        gn_pass = lambda: ops.group_norm(y0, g, b, silu=True, dtype=dt)
+        r = med_interleaved([plain, stats, gn_pass, gn_cols])
+        print(f"conv3x3 {hw}x{hw} C{C}: plain {r[0][0]*1e3:.3f} ms | +colstats {r[1][0]*1e3:.3f} ms || GN(stats pass + apply) {r[2][0]*1e3:.3f} ms | "
+              f"GN(cols + apply) {r[3][0]*1e3:.3f} ms", flush=True)
+    M, C = 196608, 320
+    A = torch.randn(M, C, device=dev).to(dt)
+    W = (torch.randn(C, C, device=dev) * 0.05).to(dt)
+    R = torch.randn(M, C, device=dev)
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    pe = torch.randn(32, C, device=dev)
+    sep = lambda: ops.layer_norm(ops.gemm(A, W, bias=b, residual=R, out_f32=True), g, b, dtype=dt)
+    fus = lambda: ops.gemm(A, W, bias=b, residual=R, out_f32=True, ln=dict(gamma=g, beta=b))
+    fus_pe = lambda: ops.gemm(A, W, bias=b, residual=R, out_f32=True, ln=dict(gamma=g, beta=b, pe=pe, rows_per_frame=4096, pe_frames=24))
+    only = lambda: ops.gemm(A, W, bias=b, residual=R, out_f32=True)
+    r = med_interleaved([only, sep, fus, fus_pe])
+    print(f"gemm+res32 M{M} N320 K320: gemm {r[0][0]*1e3:.3f} ms | gemm + layer_norm {r[1][0]*1e3:.3f} ms | fused LN {r[2][0]*1e3:.3f} ms | "
+          f"fused LN+pe {r[3][0]*1e3:.3f} ms", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
@@ -82,6 +155,8 @@ def main():
     ap.add_argument("--ab", default="", help="A/B table of the gemm_kernel family over tuning-knob settings, e.g. "
                     "'MIMO_GEMM_CFG=3;MIMO_GEMM_CFG=4,MIMO_GEMM_STAGGER=1' (settings separated by ';')")
     ap.add_argument("--vae", action="store_true", help="time VAE encode/decode + pose guider on 8 frames at 512x512 instead")
+    ap.add_argument("--attn-ab", action="store_true", help="d = 40 attention: legacy vs attn40_kernel program orders (tune build)")
+    ap.add_argument("--fused", action="store_true", help="epilogue column statistics / fused LayerNorm vs the launches they replace")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda:0")
@@ -89,6 +164,10 @@ def main():
     print(f"# dtype={a.dtype} device={torch.cuda.get_device_name(0)}")
     if a.ab:
         return ab_table(a.ab.split(";"), dt, dev, n)
+    if a.attn_ab:
+        return attn_ab(dt, dev)
+    if a.fused:
+        return fused_paths(dt, dev)
     if a.vae:
         from mimo_amd.vae import AutoencoderKL, PoseGuider
         with torch.device(dev):
