@@ -256,6 +256,49 @@ int mimo_window_accumulate(const float* pred, int64_t ld, const int* frames, int
 int mimo_tokens_to_image(const void* in, int in_is_f32, int dtype, int64_t ld, int n, int H, int W,
                          float* out, void* stream);
 
+
+/* ---------------------------------------------------------------------------------
+ * Image kernels either side of the denoising path: byte-exact integer / IEEE work.
+ * --------------------------------------------------------------------------------- */
+/* One separable pass of Pillow's 8-bit resampler (PIL.Image.resize; Pillow src/libImaging/Resample.c):
+ *   dst[img, y, x, c] = clip8((2^21 + sum_j src[.. first + j ..] * coeffs[o][j]) >> 22), o = x (horizontal) or y.
+ * bounds int32 [out][2] = (first source index, tap count), coeffs int32 [out][ksize]: Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc, computed on the host (mimo_amd/image.py).  A horizontal then a vertical pass equal
+ * Image.resize bit for bit.  src: uint8, or fp32 quantised on the fly as (uint8)(v * 255.0f) — the
+ * `(image * 255).astype(np.uint8)` of run_edit.py:267 — addressed by element strides (image, row, column, channel), so the
+ * pipeline's [3, F, H, W] video tensor is read in place.  dst: uint8 [n, Hd, Wd, C] contiguous.
+ *   replaces: VaeImageProcessor LANCZOS resize (pipeline_pose2vid_long_edit_bkfill_roiclip.py:424-457), the (224, 224)
+ *   bicubic resize before CLIPImageProcessor (:379-384), res_image_pil.resize((pad_w, pad_h)) (run_edit.py:268-269). */
+int mimo_resample_pass_u8(const void* src, int src_is_f32, int64_t src_stride_n, int64_t src_stride_y,
+                          int64_t src_stride_x, int64_t src_stride_c, void* dst, int n, int Hd, int Wd, int C,
+                          const int* bounds, const int* coeffs, int ksize, int horizontal, void* stream);
+/* uint8 [npix, C] -> half16 tokens [npix, Cpad] = x / 255 (fp32), optionally 2 x - 1; channels >= C zero
+ *   (VaeImageProcessor.preprocess as configured at pipeline_...roiclip.py:73-80). */
+int mimo_u8_to_tokens(int dtype, const void* src, int64_t npix, int C, int Cpad, int two_x_minus_1, void* dst,
+                      void* stream);
+/* uint8 [n, HW, C] -> fp32 planar [n, C, HW] = (x * rescale - mean[c]) / std[c]  (CLIPImageProcessor rescale + normalize) */
+int mimo_u8_to_planar_f32(const void* src, int n, int64_t HW, int C, float rescale, const float* mean,
+                          const float* stdv, float* dst, void* stream);
+/* The per-frame compositing of run_edit.py:253-304 in one pass over the full-resolution frame:
+ *   canvas = white; paste crop[top : pad_h - bottom, left : pad_w - right] at (w_min, h_min)
+ *   res = canvas * mask_full + bk * (1 - mask_full)          float32; mask_full = 0 outside mask placed at (h_min, w_min)
+ *   res = res * (1 - occ / 255.0) + vid * (occ / 255.0)      float64, when occ != NULL (channel 0 of occ)
+ *   res = prev * (1 - factor) + res * factor                 float64 (a float32 res * factor stays float32), when prev != NULL
+ *   out = (uint8) res                                        truncation, as ndarray.astype(np.uint8)
+ * Every operation is separately rounded in numpy's width and order: the uint8 result is the reference's. */
+typedef struct mimo_composite_params {
+  const void* crop;   /* uint8 [pad_h, pad_w, 3]: the generated frame resized to the padded clip size */
+  const float* mask;  /* fp32 [mh, mw]: the (already resized) alpha mask of tools/util.py:397-447 */
+  const void* bk;     /* uint8 [H, W, 3] inpainted background frame */
+  const void* occ;    /* uint8 [H, W, 3] occluder mask frame, or NULL */
+  const void* vid;    /* uint8 [H, W, 3] original frame (needed with occ) */
+  const void* prev;   /* uint8 [H, W, 3] result of the previous clip for this frame (overlap cross-fade), or NULL */
+  void* out;          /* uint8 [H, W, 3]; may alias prev */
+  double factor;      /* (i - start_i + 1) / (overlay + 1) */
+  int pad_h, pad_w, top, bottom, left, right, w_min, h_min, mh, mw, H, W;
+} mimo_composite_params;
+int mimo_composite_frame(const mimo_composite_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

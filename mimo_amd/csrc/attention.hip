@@ -374,7 +374,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 // ------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int DT, int ORDER>
+// ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tile's K / V):
+// the compute-only time of the loop, for telling a memory-latency bound from an issue bound
+template <int DT, int ORDER, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
   constexpr int KROWB = 80;                 // K tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
@@ -630,12 +632,12 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   // ---- one KV tile; CUR (the LDS buffer pair it reads) is a compile-time constant ----
   auto tile = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
-    if (t + 1 < T) dma_k(t + 1, CUR ^ 1);  // buffer CUR^1 was last read in iteration t-1 (barrier passed)
+    if (t + 1 < T && ABL != 1) dma_k(t + 1, CUR ^ 1);  // buffer CUR^1 was last read in iteration t-1 (barrier passed)
     const bool s2 = t >= T0;
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
     const bool special = (t == 0) | (kv0 + KV_TILE > nk);  // wave-uniform: first / ragged tiles take the slow path
-    const unsigned char* kbuf = smem + CUR * KBUF;
+    const unsigned char* kbuf = smem + (ABL == 1 ? 0 : CUR) * KBUF;
     const unsigned char* vbuf = smem + CUR * VBUF + vaddr;
 
     uint4 kf[2][3];
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     for (int u = 0; u < 2; ++u) {
       kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB);
       kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB + 32);
-      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + CUR * kaddr2_d + (h2 ? 0 : u * 32 * KROWB));
+      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + (ABL == 1 ? 0 : CUR) * kaddr2_d + (h2 ? 0 : u * 32 * KROWB));
     }
     f32x16 sa[2], sb[2];
     uint32_t wa[2][8], wb[2][8];
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     pv(vbuf, 1, pb);
     if (t + 1 < T) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's K(t+1) DMA has landed
-      if (t + 2 < T) issue_v(t + 2);
+      if (t + 2 < T && ABL != 1) issue_v(t + 2);
       __syncthreads();                                    // publishes tile t+1; every wave is done with buffers CUR
     }
   };
@@ -880,7 +882,13 @@ static inline bool attn40_legacy() { return tune_env("MIMO_ATTN40_LEGACY", 0) !=
 template <int DT>
 static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(((a.Nq + 255) / 256) * a.heads * a.B));
-  const int order = tune_env("MIMO_ATTN40_ORDER", 0);
+  const int order = tune_env("MIMO_ATTN40_ORDER", 1);
+#ifdef MIMO_TUNE
+  if (tune_env("MIMO_ATTN40_ABLATE", 0) == 1) {
+    hipLaunchKernelGGL((attn40_kernel<DT, 1, 1>), grid, dim3(256), 0, st, a);
+    return;
+  }
+#endif
   if (order == 1) hipLaunchKernelGGL((attn40_kernel<DT, 1>), grid, dim3(256), 0, st, a);
   else if (order == 2) hipLaunchKernelGGL((attn40_kernel<DT, 2>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn40_kernel<DT, 0>), grid, dim3(256), 0, st, a);

@@ -250,57 +250,71 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmArgs& g, f32x4 (&a
       imgb = ((unsigned)(M0 + rowb) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
     }
     const unsigned slab_local = (unsigned)((wm * 16 * MT) >> 5) + (unsigned)sp;
+    // 1: every load of the slab back to back (interleaved stores would serialise them: vmcnt retires in order)
+    f32x4 va[NR], vb[NR], ra[NR], rb[NR];
+    bool okc[NR];
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) {
       const int n = N0 + col0 + ni * 16;
-      const bool ok = n < g.N;
-      const f32x4 bv = ld4(r_bias, ok ? (unsigned)n * 4u : OOB);
-      f32x4 va = acc[ni][2 * sp] + bv, vb = acc[ni][2 * sp + 1] + bv;
+      okc[ni] = n < g.N;
+      const f32x4 bv = ld4(r_bias, okc[ni] ? (unsigned)n * 4u : OOB);
+      va[ni] = acc[ni][2 * sp] + bv;
+      vb[ni] = acc[ni][2 * sp + 1] + bv;
       if (g.img_bias) {
-        va += ld4(r_imgb, ok ? imga + (unsigned)n * 4u : OOB);
-        vb += ld4(r_imgb, ok ? imgb + (unsigned)n * 4u : OOB);
-      }
-      if (do_silu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { va[r] = silu_f(va[r]); vb[r] = silu_f(vb[r]); }
+        va[ni] += ld4(r_imgb, okc[ni] ? imga + (unsigned)n * 4u : OOB);
+        vb[ni] += ld4(r_imgb, okc[ni] ? imgb + (unsigned)n * 4u : OOB);
       }
       if (g.res) {
         if (res_f32) {
-          va += ld4(r_res, ok ? (rowa * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
-          vb += ld4(r_res, ok ? (rowb * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
+          ra[ni] = ld4(r_res, okc[ni] ? (rowa * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
+          rb[ni] = ld4(r_res, okc[ni] ? (rowb * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
         } else {
-          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, ok ? (rowa * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
-          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, ok ? (rowb * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
-          va += (f32x4){HT<DT>::to_f((uint16_t)(ha.x & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.x >> 16)),
-                        HT<DT>::to_f((uint16_t)(ha.y & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.y >> 16))};
-          vb += (f32x4){HT<DT>::to_f((uint16_t)(hb.x & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.x >> 16)),
-                        HT<DT>::to_f((uint16_t)(hb.y & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.y >> 16))};
+          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowa * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowb * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+          ra[ni] = (f32x4){HT<DT>::to_f((uint16_t)(ha.x & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.x >> 16)),
+                           HT<DT>::to_f((uint16_t)(ha.y & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.y >> 16))};
+          rb[ni] = (f32x4){HT<DT>::to_f((uint16_t)(hb.x & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.x >> 16)),
+                           HT<DT>::to_f((uint16_t)(hb.y & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.y >> 16))};
         }
       }
-      va *= g.out_scale;
-      vb *= g.out_scale;
-      const unsigned oa = ok ? (rowa * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
-      const unsigned ob = ok ? (rowb * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
+    }
+    // 2: finish the values and store them
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const int n = N0 + col0 + ni * 16;
+      if (do_silu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { va[ni][r] = silu_f(va[ni][r]); vb[ni][r] = silu_f(vb[ni][r]); }
+      }
+      if (g.res) { va[ni] += ra[ni]; vb[ni] += rb[ni]; }
+      va[ni] *= g.out_scale;
+      vb[ni] *= g.out_scale;
+      const unsigned oa = okc[ni] ? (rowa * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
+      const unsigned ob = okc[ni] ? (rowb * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
       if (out_f32) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va), r_out, oa, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), r_out, ob, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va[ni]), r_out, oa, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb[ni]), r_out, ob, 0, 0);
       } else {
         u32x2 o;
-        o.x = pack2<DT>(va[0], va[1]); o.y = pack2<DT>(va[2], va[3]);
+        o.x = pack2<DT>(va[ni][0], va[ni][1]); o.y = pack2<DT>(va[ni][2], va[ni][3]);
         __builtin_amdgcn_raw_buffer_store_b64(o, r_out, oa, 0, 0);
-        o.x = pack2<DT>(vb[0], vb[1]); o.y = pack2<DT>(vb[2], vb[3]);
+        o.x = pack2<DT>(vb[ni][0], vb[ni][1]); o.y = pack2<DT>(vb[ni][2], vb[ni][3]);
         __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ob, 0, 0);
       }
-      // slab statistics of this column chunk: 32 rows = (rows li of tile a) + (rows li of tile b)
+    }
+    // 3: slab statistics (32 rows = rows li of tile a + rows li of tile b) while the stores drain
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const int n = N0 + col0 + ni * 16;
       f32x4 mean, m2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mean[r] = row16_sum(va[r] + vb[r]) * (1.0f / 32.0f);
+      for (int r = 0; r < 4; ++r) mean[r] = row16_sum(va[ni][r] + vb[ni][r]) * (1.0f / 32.0f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float da = va[r] - mean[r], db = vb[r] - mean[r];
+        const float da = va[ni][r] - mean[r], db = vb[ni][r] - mean[r];
         m2[r] = row16_sum(fmaf(da, da, db * db));
       }
-      const unsigned cso = (ok && li == 0) ? (slab_local * 2u * (unsigned)g.N + (unsigned)n) * 4u : OOB;
+      const unsigned cso = (okc[ni] && li == 0) ? (slab_local * 2u * (unsigned)g.N + (unsigned)n) * 4u : OOB;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean), r_cs, cso, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m2), r_cs, cso == OOB ? OOB : cso + (unsigned)g.N * 4u, 0, 0);
     }
@@ -344,34 +358,48 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
   auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
   };
-  // ---- 1: the ordinary epilogue; the stored values stay in `acc` ----
+  // ---- 1: the ordinary epilogue; the stored values stay in `acc`.  All loads first, then all stores: interleaved
+  // they serialise (vmcnt retires in order, a load behind a store waits for the store's acknowledgement) ----
+  {
+    f32x4 rr[NR][MT];
 #pragma unroll
-  for (int ni = 0; ni < NR; ++ni) {
-    const unsigned n = (unsigned)(col0 + ni * 16);
-    const f32x4 bv = ld4(r_bias, n * 4u);
+    for (int ni = 0; ni < NR; ++ni) {
+      const unsigned n = (unsigned)(col0 + ni * 16);
+      const f32x4 bv = ld4(r_bias, n * 4u);
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const unsigned row = (unsigned)(row0 + mi * 16);
-      f32x4 v = acc[ni][mi] + bv;
-      if (g.img_bias) v += ld4(r_imgb, ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + n * 4u);
-      if (g.res) {
-        if (res_f32) {
-          v += ld4(r_res, (row * (unsigned)g.ldr + n) * 4u);
-        } else {
-          const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, (row * (unsigned)g.ldr + n) * 2u, 0, 0);
-          v += (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
-                       HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+      for (int mi = 0; mi < MT; ++mi) {
+        const unsigned row = (unsigned)(row0 + mi * 16);
+        acc[ni][mi] += bv;
+        if (g.img_bias) acc[ni][mi] += ld4(r_imgb, ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + n * 4u);
+        if (g.res) {
+          if (res_f32) {
+            rr[ni][mi] = ld4(r_res, (row * (unsigned)g.ldr + n) * 4u);
+          } else {
+            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, (row * (unsigned)g.ldr + n) * 2u, 0, 0);
+            rr[ni][mi] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
+                                 HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+          }
         }
       }
-      v *= g.out_scale;
-      acc[ni][mi] = v;
-      const unsigned ooff = (row * (unsigned)g.ldo + n) * esz_o;
-      if (out_f32) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
-      } else {
-        u32x2 o;
-        o.x = pack2<DT>(v[0], v[1]); o.y = pack2<DT>(v[2], v[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const unsigned n = (unsigned)(col0 + ni * 16);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const unsigned row = (unsigned)(row0 + mi * 16);
+        f32x4 v = acc[ni][mi];
+        if (g.res) v += rr[ni][mi];
+        v *= g.out_scale;
+        acc[ni][mi] = v;
+        const unsigned ooff = (row * (unsigned)g.ldo + n) * esz_o;
+        if (out_f32) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+        } else {
+          u32x2 o;
+          o.x = pack2<DT>(v[0], v[1]); o.y = pack2<DT>(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+        }
       }
     }
   }
@@ -385,7 +413,8 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
       s[mi] += __shfl_xor(s[mi], 32, 64);
       if (lg == 0) redp[(wm * 16 * MT + mi * 16 + li) * WN + wn] = s[mi];
     }
-    __syncthreads();
+    // LDS-only rendezvous: a __syncthreads() would also wait (vmcnt) for the epilogue's global stores
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const float* rp = redp + (wm * 16 * MT + mi * 16 + li) * WN;

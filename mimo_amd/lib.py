@@ -30,6 +30,12 @@ class EpilogueExt(ctypes.Structure):  # mimo_epilogue_ext
                 ("ln_eps", c_f), ("ln_pe_frames", c_i), ("ln_rows_per_frame", c_i64)]
 
 
+class CompositeParams(ctypes.Structure):  # mimo_composite_params
+    _fields_ = [("crop", c_vp), ("mask", c_vp), ("bk", c_vp), ("occ", c_vp), ("vid", c_vp), ("prev", c_vp), ("out", c_vp),
+                ("factor", ctypes.c_double)] + [(n, c_i) for n in ("pad_h", "pad_w", "top", "bottom", "left", "right",
+                                                                 "w_min", "h_min", "mh", "mw", "H", "W")]
+
+
 # name -> argtypes, mirrors include/mimo_hip.h one to one
 SIGNATURES = {
     "mimo_version": [],
@@ -56,6 +62,10 @@ SIGNATURES = {
     "mimo_cfg_ddim_step": [c_vp, c_vp, c_vp, c_i, c_i, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_vp],
     "mimo_window_accumulate": [c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_i64, c_vp, c_vp, c_vp],
     "mimo_tokens_to_image": [c_vp, c_i, c_i, c_i64, c_i, c_i, c_i, c_vp, c_vp],
+    "mimo_resample_pass_u8": [c_vp, c_i, c_i64, c_i64, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_i, c_vp],
+    "mimo_u8_to_tokens": [c_i, c_vp, c_i64, c_i, c_i, c_i, c_vp, c_vp],
+    "mimo_u8_to_planar_f32": [c_vp, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_vp],
+    "mimo_composite_frame": [ctypes.POINTER(CompositeParams), c_vp],
 }
 
 

@@ -313,7 +313,7 @@ class SpatialTransformer(HipModule):
         blk = self.transformer_blocks[0]
         t, n1 = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=blk.ln1(ctx.dtype))
         z = blk.run(ctx, t, n, H * W, n1=n1)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=True)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=H * W)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
 
 
@@ -399,5 +399,5 @@ class MotionModule(HipModule):
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
             t, u = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True, ln=ln[i + 1])
         z = _ff_run(ctx, p, t, u, out_f32=False)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=True)
+        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=H * W)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))

@@ -101,10 +101,17 @@ def _workspace(device):
     return ws
 
 
-# GroupNorm column statistics (mimo_epilogue_ext.colstats): a producer called with colstats=True attaches the
-# fp32 [M/32, 2, N] tensor to its output as `_cs`; group_norm() consumes it instead of re-reading the tensor.
-# Rows M below this keep split-K available instead (the 8x8 level, where one more pass over 16 MB is cheaper).
-COLSTATS_MIN_ROWS = 8192
+# GroupNorm column statistics (mimo_epilogue_ext.colstats): a producer called with colstats=<rows per image> attaches
+# the fp32 [M/32, 2, N] tensor to its output as `_cs`; group_norm() consumes it instead of re-reading the tensor.
+# The decision depends on the IMAGE size only, never on the batch: a frame's statistics must be computed the same way
+# however many frames share the launch (the sharded long-clip mode reproduces the single-GPU bits).  Images below
+# COLSTATS_MIN_HW pixels keep split-K available instead (the 8x8 level: one more pass over 16 MB is the cheaper way).
+COLSTATS_MIN_HW = 256
+
+
+def _want_colstats(rows_per_image, M):
+    hw = int(rows_per_image or 0)
+    return hw >= COLSTATS_MIN_HW and hw % 32 == 0 and M % hw == 0
 
 
 def with_stats(t, cs):
@@ -147,7 +154,8 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
          geglu=False, out=None, out_scale=1.0, colstats=False, ln=None):
     """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1).
 
-    colstats=True: also emit GroupNorm column statistics of `out` (attached as out._cs) when the shape allows.
+    colstats=<rows per image>: also emit GroupNorm column statistics of `out` (attached as out._cs) when the image size
+    allows (see COLSTATS_MIN_HW).
     ln=dict(gamma, beta[, eps, pe, rows_per_frame, pe_frames]): also return LayerNorm(out) (+ pe) as a half tensor —
     fused into the epilogue when N == 320, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out)."""
     _chk(a, "a")
@@ -177,7 +185,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
                and (residual is None or ldr == N)
                and (ln.get("pe") is None or (ln.get("rows_per_frame", 0) % 128 == 0 and ln.get("pe_frames", 0) > 0)))
     cs = ln_out = None
-    if colstats and not fuse_ln and not geglu and M % 32 == 0 and M >= COLSTATS_MIN_ROWS and N % 4 == 0:
+    if not fuse_ln and not geglu and N % 4 == 0 and _want_colstats(colstats, M):
         cs = torch.empty((M // 32, 2, N), device=a.device, dtype=torch.float32)
     if fuse_ln:
         ln_out = torch.empty((M, N), device=a.device, dtype=a.dtype)
@@ -239,7 +247,7 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
         flags |= L.EPI_NO_SPLITK
     M = n * Ho * Wo
     cs = None
-    if colstats and M % 32 == 0 and (Ho * Wo) % 32 == 0 and M >= COLSTATS_MIN_ROWS and cout % 4 == 0:
+    if colstats and cout % 4 == 0 and _want_colstats(Ho * Wo, M):
         cs = torch.empty((M // 32, 2, cout), device=x.device, dtype=torch.float32)
     fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
     _count(fl)

@@ -16,7 +16,6 @@ Ranks without a unit (world > units) take part with zero slots.
 """
 import math
 
-import numpy as np
 import torch
 
 from . import ops
@@ -29,17 +28,6 @@ VAE_SCALE = 0.18215  # hard-coded by the reference pipeline (:115,431,439)
 class Pose2VideoPipelineOutput:
     def __init__(self, videos):
         self.videos = videos
-
-
-def preprocess_image(image, height, width, normalize, scale_factor=8):
-    """diffusers VaeImageProcessor.preprocess as configured at pipeline :73-80: RGB, PIL LANCZOS resize to
-    (width, height) rounded down to a multiple of 8, /255, NCHW, optional 2x-1 (host-side, PIL)."""
-    from PIL import Image
-    image = image.convert("RGB")
-    w, h = width - width % scale_factor, height - height % scale_factor
-    image = image.resize((w, h), resample=Image.LANCZOS)
-    t = torch.from_numpy(np.array(image).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
-    return 2.0 * t - 1.0 if normalize else t
 
 
 def plan_units(num_windows, cfg, rank, world):
@@ -227,7 +215,6 @@ class Pose2VideoPipeline:
         self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
         self.stage_times = None     # dict -> accumulates per-stage milliseconds (HIP events) of run_tensors
         self._graphs = {}
-        self._clip_processor = None
 
     def to(self, device=None, dtype=None):
         for m in (self.vae, self.image_encoder, self.reference_unet, self.denoising_unet, self.pose_guider):
@@ -247,11 +234,15 @@ class Pose2VideoPipeline:
 
     # ------------------------------------------------------------------------------------------
     def _encode_frames(self, images):
-        """images [n,3,H,W] in [-1,1] (device) -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
+        """images [n,3,H,W] in [-1,1] (device), or half tokens [n,H,W,8] from image.vae_preprocess
+        -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
         dt = self.vae.compute_dtype
         outs = []
         for i in range(0, images.shape[0], self.vae_batch):
-            tok = ops.ncfhw_to_tokens(images[i:i + self.vae_batch].contiguous()[:, :, None], dt, cpad=8)
+            if images.shape[-1] == 8 and images.dtype == dt:
+                tok = images[i:i + self.vae_batch].contiguous()
+            else:
+                tok = ops.ncfhw_to_tokens(images[i:i + self.vae_batch].float().contiguous()[:, :, None], dt, cpad=8)
             outs.append(self.vae.encode_tokens(tok))
         return torch.cat(outs) * VAE_SCALE
 
@@ -306,19 +297,22 @@ class Pose2VideoPipeline:
                 marks.append((name, ev))
 
         mark("start")
-        ref_lat = self._encode_frames(ref_image.to(dev).float())               # [1,h,w,4]
+        ref_lat = self._encode_frames(ref_image.to(dev))                       # [1,h,w,4]
 
         def pose_fn(frames):
-            tok = ops.ncfhw_to_tokens(frames.contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
+            if frames.shape[-1] == 8 and frames.dtype == self.pose_guider.compute_dtype:
+                tok = frames  # already half tokens (image.vae_preprocess)
+            else:
+                tok = ops.ncfhw_to_tokens(frames.float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
             return torch.cat([self.pose_guider.run_tokens(tok[i:i + self.vae_batch].contiguous())
                               for i in range(0, tok.shape[0], self.vae_batch)])
 
         if world > 1:  # one long clip over the ranks: the per-frame stages are sharded too
-            bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev).float(), rank, world, self.dist_group).to(dt)
-            pose_tok = sharded_frames(pose_fn, pose_images.to(dev).float(), rank, world, self.dist_group)
+            bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev), rank, world, self.dist_group).to(dt)
+            pose_tok = sharded_frames(pose_fn, pose_images.to(dev), rank, world, self.dist_group)
         else:
-            bk_tok = self._encode_frames(bk_images.to(dev).float()).to(dt)     # [F,h,w,4]
-            pose_tok = pose_fn(pose_images.to(dev).float())                    # fp32 [F,h,w,C0]
+            bk_tok = self._encode_frames(bk_images.to(dev)).to(dt)             # [F,h,w,4]
+            pose_tok = pose_fn(pose_images.to(dev))                            # fp32 [F,h,w,C0]
 
         # reference UNet at t = 0 (pipeline :480-490): only the cond element's banks are ever read, and
         # everything after the last bank write is dead code -> run b = 1 with early exit.
@@ -426,14 +420,12 @@ class Pose2VideoPipeline:
         if eta != 0.0 or context_batch_size != 1 or interpolation_factor != 1:
             raise NotImplementedError("eta=0, context_batch_size=1, interpolation_factor=1 (the reference defaults) only")
         dev = self.device
-        # CLIP image embedding (pipeline :379-384).  The image encoder is outside the accelerated path
-        # (SURVEY.md §8f rank 1): any module returning `.image_embeds` works (transformers CLIPVisionModelWithProjection).
-        if self._clip_processor is None:
-            from transformers import CLIPImageProcessor
-            self._clip_processor = CLIPImageProcessor()
-        clip_image = self._clip_processor.preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        from . import image as IM
+        # CLIP image embedding (pipeline :379-384): `ref_image.resize((224, 224))` + CLIPImageProcessor run on the device
+        # (PIL-exact bicubic resample + rescale / normalise); any module returning `.image_embeds` works as the encoder.
+        clip_image = IM.clip_preprocess(ref_image, dev)
         enc_dtype = getattr(self.image_encoder, "dtype", torch.float32)
-        clip_embeds = self.image_encoder(clip_image.to(dev, dtype=enc_dtype)).image_embeds
+        clip_embeds = self.image_encoder(clip_image.to(dtype=enc_dtype)).image_embeds
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         # prepare_latents (:149-183): CPU generator draws on CPU in the embedding dtype, then moves
         shape = (1, 4, video_length, h, w)
@@ -442,9 +434,12 @@ class Pose2VideoPipeline:
             latents = torch.randn(shape, generator=generator, device="cpu", dtype=clip_embeds.dtype).to(dev)
         else:
             latents = torch.randn(shape, generator=generator, device=dev, dtype=clip_embeds.dtype)
-        ref_t = preprocess_image(ref_image, height, width, True)
-        bk_t = torch.cat([preprocess_image(im, height, width, True) for im in vid_bk_images])
-        pose_t = torch.cat([preprocess_image(im, height, width, False) for im in pose_images])
+        # VaeImageProcessor.preprocess (:424-457) on the device: the host only decodes the PIL images to raw bytes;
+        # LANCZOS resize, /255, 2x-1 and the token layout are kernels (image.vae_preprocess)
+        vdt = self.vae.compute_dtype
+        ref_t = IM.vae_preprocess([ref_image], height, width, True, vdt, dev)
+        bk_t = IM.vae_preprocess(list(vid_bk_images), height, width, True, vdt, dev)
+        pose_t = IM.vae_preprocess(list(pose_images), height, width, False, self.pose_guider.compute_dtype, dev)
         cb = None
         if callback is not None:
             cb = lambda i, t, lat: callback(i, t, lat) if i % callback_steps == 0 else None

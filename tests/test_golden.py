@@ -166,6 +166,50 @@ def test_hip_config2_pipeline_vs_reference_golden(full_models):
     line = "config-2 (512x512, 24 f, 20 steps) latents rel_l2 after steps 0/9/19: " + " ".join("%.2e" % e for e in errs)
     print(line)
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt"), "a") as f:
-        f.write(line + "\n")
+    vpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_512_24f_video_frames.safetensors")
+    if os.path.exists(vpath):  # decoded frames 0 and 23 of the reference's final latents (oracle VAE decode)
+        V = gold("config2_512_24f_video_frames.safetensors")
+        verr = [rel_l2(video[0, :, f].float().cpu(), V[f"video_frame{f}"]) for f in (0, 23)]
+        line += " | decoded video frames 0/23: " + " ".join("%.2e" % e for e in verr)
+        print(line)
+    _report(line)
     assert max(errs) < 1e-3  # north_star bar: 1e-3 relative on the denoised latents of the headline configuration
+    if os.path.exists(vpath):
+        assert max(verr) < 1.5e-3  # the fp16 VAE decoder on top of the latents' own error
+
+
+def _report(line):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.txt"), "a") as f:
+        f.write(line + "\n")
+
+
+@pytest.mark.gpu
+def test_hip_multiwindow_call_vs_reference_golden(full_models):
+    """The windowed long-clip path at full size, through `__call__` on BOTH sides: 512x512, F = 48 -> three 24-frame
+    context windows (starts 0, 20, 40; the last wraps to frame 0; frames 0-3, 20-23, 40-43 are averaged over two
+    windows), 4 DDIM steps, CFG 3.5, PIL inputs.  Fixture: the reference's OWN Pose2VideoPipeline.__call__
+    (pipeline_pose2vid_long_edit_bkfill_roiclip.py:338-578) on CPU fp32 (oracle/make_golden.py multiwindow, 48 min)."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    from oracle.make_golden import MW, FakeClip, multiwindow_inputs
+    G = gold("multiwindow_512_48f_4steps.safetensors")
+    dev = torch.device("cuda:0")
+    size, F, steps = MW["size"], MW["F"], MW["steps"]
+    m = full_models
+    pipe = Pose2VideoPipeline(m["vae"], FakeClip().to(dev), m["ref"], m["den"], m["pose"],
+                              DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    ref_img, poses, bks = multiwindow_inputs(size, F)
+    traj = []
+    video = pipe(ref_img, poses, bks, size, size, F, steps, MW["guidance"], generator=torch.manual_seed(MW["seed"]),
+                 callback=lambda i, t, lat: traj.append(lat.detach().float().cpu().clone()), callback_steps=1).videos
+    assert len(traj) == steps and video.shape == (1, 3, F, size, size)
+    e0, e3 = rel_l2(traj[0], G["latents_step0"]), rel_l2(traj[-1], G[f"latents_step{steps-1}"])
+    v0, v47 = rel_l2(video[0, :, 0], G["video_frame0"]), rel_l2(video[0, :, F - 1], G[f"video_frame{F-1}"])
+    line = (f"multi-window (512x512, 48 f = 3 wrapped windows, 4 steps, __call__) latents rel_l2 after steps 0/3: {e0:.2e} {e3:.2e}"
+            f" | decoded frames 0/47: {v0:.2e} {v47:.2e}")
+    print(line)
+    _report(line)
+    assert e0 < 1e-3 and e3 < 1.5e-3 and max(v0, v47) < 2e-3

@@ -310,3 +310,74 @@ def test_pretrained_weights_layout_roundtrip(tmp_path):
 
     assert same(denoising_unet, sd3) and same(reference_unet, o2.state_dict()) and same(pose_guider, opg.state_dict())
     assert same(vae, ovae.state_dict()) and same(image_enc, oclip.state_dict())
+
+
+def _apply_pass(img, bounds, kk, axis):
+    """numpy application of one resampling pass with the integer tables of mimo_amd.image.pil_coeffs (what the HIP kernel does)."""
+    import numpy as np
+    img = np.moveaxis(img, axis, 0)
+    out = np.empty((bounds.shape[0],) + img.shape[1:], np.uint8)
+    for o in range(bounds.shape[0]):
+        first, count = bounds[o]
+        acc = np.full(img.shape[1:], 1 << 21, np.int64)
+        for j in range(count):
+            acc += img[first + j].astype(np.int64) * int(kk[o, j])
+        out[o] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def test_pil_coefficient_tables_reproduce_pil_resize():
+    """The fixed-point tables mimo_amd/image.py hands to mimo_resample_pass_u8 are Pillow's own (Resample.c
+    precompute_coeffs + normalize_coeffs_8bpc): applying them in integer arithmetic equals PIL.Image.resize bit for bit."""
+    import numpy as np
+    from PIL import Image
+    from mimo_amd.image import pil_coeffs
+    rs = np.random.RandomState(0)
+    for (H, W, oh, ow, name, pil) in [(64, 48, 80, 96, "bicubic", Image.BICUBIC), (100, 120, 53, 37, "bicubic", Image.BICUBIC),
+                                      (90, 70, 64, 64, "lanczos", Image.LANCZOS), (33, 47, 96, 128, "lanczos", Image.LANCZOS),
+                                      (98, 98, 64, 64, "lanczos", Image.LANCZOS)]:
+        a = rs.randint(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(a).resize((ow, oh), resample=pil))
+        x = _apply_pass(a, *pil_coeffs(W, ow, name), axis=1)
+        x = _apply_pass(x, *pil_coeffs(H, oh, name), axis=0)
+        assert np.array_equal(x, ref)
+
+
+def test_edit_compositing_oracle_is_self_consistent():
+    """oracle/edit.py on a one-clip template without occluder and with an all-ones mask pastes the resized frame as is."""
+    import numpy as np
+    from PIL import Image
+    from oracle import edit as OE
+    H = W = 32
+    video = torch.rand(3, 2, H, W, generator=torch.Generator().manual_seed(0))
+    bk = [Image.fromarray(np.full((48, 64, 3), 7, np.uint8))] * 2
+    out = OE.composite(video, [[0, 1]], [(8, 40, 4, 36)], [[32, 32]] * 2, [(0, 0, 0, 0)] * 2, bk, bk, None,
+                       [np.ones((32, 32), np.float32)] * 2, 4, 2)
+    frame = (video[:, 0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    assert np.array_equal(out[0][4:36, 8:40], frame) and int(out[0][0, 0, 0]) == 7
+
+
+@pytest.mark.reference
+def test_mask_mode_matches_reference_get_mask():
+    """mimo_amd.edit.get_mask == tools/util.py:397-447 get_mask.  tools/util.py imports cv2 at module level (absent
+    here), so only the `mask_mode` table and the `get_mask` function are taken from its source (ast) and executed."""
+    import ast
+    import random
+    from mimo_amd import edit as E
+    src = open("/root/reference/tools/util.py").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name == "get_mask") or
+            (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "mask_mode")]
+    ns = {}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "tools/util.py", "exec"), ns)
+    assert ns["mask_mode"] == E.MASK_MODE
+
+    class Img:
+        size = (128, 96)
+    masks = list(range(16))
+    rnd = random.Random(0)
+    for _ in range(2000):
+        xs = sorted(rnd.choice([-3, 0, 5, 60, 127, 128, 140]) for _ in range(2))
+        ys = sorted(rnd.choice([-2, 0, 7, 50, 95, 96, 100]) for _ in range(2))
+        bbox = (xs[0], xs[1], ys[0], ys[1])
+        assert ns["get_mask"](masks, bbox, Img) == E.get_mask(masks, bbox, Img)
