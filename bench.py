@@ -123,11 +123,12 @@ def measure_forward(pipe, dev, dtype, size, iters=3):
     unet.run_tokens(x, 499, ehs, 2, 24, pose)
     torch.cuda.synchronize()
     fam = {}
-    for name, e0, e1, fl in ops.EVENTS:
-        d = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0})
+    for name, e0, e1, fl, nb in ops.EVENTS:
+        d = fam.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
         d["launches"] += 1
         d["ms"] += e0.elapsed_time(e1)
         d["flops"] += fl
+        d["bytes"] += nb
     ops.EVENTS = None
     reader.clear()
     writer.clear()
@@ -138,26 +139,44 @@ def pmc_traffic(family):
     """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     over tools/profile_forward.py (same models, same shapes; PMC passes cannot run inside the timed region).
     None when no summary has been committed for this build (tools/pmc_traffic.py writes it)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_forward_traffic.json")
-    try:
-        d = json.load(open(path))[family]
-        return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
-                "write": d["write_bytes_per_launch"], "source": "profiles/r1_pmc_forward_traffic.json"}
-    except Exception:
-        return None
+    for name in ("r2_pmc_forward_traffic.json", "r1_pmc_forward_traffic.json"):  # newest committed summary first
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            d = json.load(open(path))[family]
+            return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
+                    "write": d["write_bytes_per_launch"], "source": "profiles/" + name}
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(clip_flops, frames, budget_s=15.0):
-    """Oracle (CPU fp32 PyTorch port of the reference path, oracle/models.py) timed on this host: one denoising-UNet
-    forward of the FULL-SIZE model on a reduced sample (latent 16x16, 2 x 4 frames), FLOPs counted by torch's
-    FlopCounterMode, extrapolated to the whole clip's executed FLOPs."""
+def cpu_baseline(clip_flops, frames, budget_s=25.0):
+    """The reference's CPU PyTorch path timed on this host: ONE denoising-UNet forward of the FULL-SIZE model at
+    BASELINE configs[0] size (latent 32x32, 2 x 8 frames: ~3.3 TFLOP, seconds per forward), FLOPs counted by torch's
+    FlopCounterMode, extrapolated to the whole clip's executed FLOPs.  Where /root/reference is mounted (this
+    container) the model is the reference's OWN src/models code behind oracle/diffusers_standin.py (kind "reference");
+    on the GPU box, where it is not, the oracle port proven equal to it (kind "port")."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import models as OM
     cores = min(os.cpu_count(), 32)  # threads actually used: more only adds oversubscription on shared hosts
     torch.set_num_threads(cores)
     t0 = time.time()
-    with torch.device("meta"):
-        m = OM.UNet3DConditionModel()
+    kind = "port"
+    m = None
+    if os.path.isdir("/root/reference/src"):
+        try:
+            from oracle.diffusers_standin import install
+            from oracle.make_golden import mm_kwargs
+            install()
+            import src.models.unet_3d_edit_bkfill as u3
+            with torch.device("meta"):
+                m = u3.UNet3DConditionModel(sample_size=64, in_channels=8, **OM.SD15_UNET_CONFIG, **mm_kwargs(8))
+            kind = "reference"
+        except Exception:
+            m = None
+    if m is None:
+        with torch.device("meta"):
+            m = OM.UNet3DConditionModel()
     m = m.to_empty(device="cpu")
     with torch.no_grad():
         for p in m.parameters():
@@ -166,28 +185,86 @@ def cpu_baseline(clip_flops, frames, budget_s=15.0):
             if isinstance(mod, (nn.GroupNorm, nn.LayerNorm)):
                 mod.weight.fill_(1.0)
                 mod.bias.zero_()
-            if isinstance(mod, OM.PositionalEncoding):
+            if hasattr(mod, "pe") and torch.is_tensor(getattr(mod, "pe")):  # PositionalEncoding buffer
                 mod.pe.copy_(OM.PositionalEncoding(mod.pe.shape[-1], mod.pe.shape[1]).pe)
     m.eval()
     build_s = time.time() - t0
-    hw, F = 16, 4
+    hw, F = 32, 8
     x = torch.randn(2, 8, F, hw, hw)
     ehs = torch.randn(2, 1, 768)
     pose = torch.randn(2, 320, F, hw, hw)
+
+    def fwd():
+        if kind == "reference":
+            return m(x, torch.tensor(499), encoder_hidden_states=ehs, pose_cond_fea=pose, return_dict=False)[0]
+        return m(x, torch.tensor(499), ehs, pose_cond_fea=pose)
+
     with torch.no_grad():
         with FlopCounterMode(display=False) as fc:
-            m(x, torch.tensor(499), ehs, pose_cond_fea=pose)  # warm-up + FLOP count
+            fwd()  # warm-up + FLOP count
         sample_flops = fc.get_total_flops()
         n, t1 = 0, time.time()
-        while n < 1 or (time.time() - t1 < budget_s and n < 10):
-            m(x, torch.tensor(499), ehs, pose_cond_fea=pose)
+        while n < 1 or (time.time() - t1 < budget_s and n < 5):
+            fwd()
             n += 1
         dt = (time.time() - t1) / n
     cpu_flops_per_s = sample_flops / dt
-    return dict(value=frames / (clip_flops / cpu_flops_per_s), unit="frames/s", cores=cores, kind="port",
-                sample=(f"oracle.models.UNet3DConditionModel (full-size, fp32, {cores} threads) forward on 2x{F} frames at "
-                        f"latent {hw}x{hw}: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => {cpu_flops_per_s/1e12:.3f} TFLOP/s; "
-                        f"extrapolated to the clip's {clip_flops/1e12:.1f} executed TFLOP (model build {build_s:.0f} s untimed)"))
+    what = "the reference's src/models UNet3DConditionModel (oracle/diffusers_standin.py)" if kind == "reference" \
+        else "oracle.models.UNet3DConditionModel (port of the reference's PyTorch path)"
+    return dict(value=frames / (clip_flops / cpu_flops_per_s), unit="frames/s", cores=cores, kind=kind,
+                sample=(f"{what}, full size, fp32, {cores} threads: denoising forward on 2x{F} frames at latent {hw}x{hw} "
+                        f"(BASELINE configs[0] size), {n} timed: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => "
+                        f"{cpu_flops_per_s/1e12:.3f} TFLOP/s; extrapolated to the clip's {clip_flops/1e12:.1f} executed TFLOP "
+                        f"(model build {build_s:.0f} s untimed)"))
+
+
+def bf16_record(pipe, dev, inp, a, fp16_forward_out):
+    """BASELINE configs[1] names bf16: the same clip with bf16 MFMA operands (identical kernels and speed class), timed
+    once, plus the rel-L2 of ONE bf16 denoising forward against the fp16 forward of the same inputs (fp16 is 7e-4 from the
+    fp32 reference; bf16's 8-bit mantissa cannot meet the 1e-3 bar) — driver-observed, not gated."""
+    dt = torch.bfloat16
+    for m in (pipe.denoising_unet, pipe.reference_unet, pipe.vae, pipe.pose_guider, pipe.image_encoder):
+        m.to(dtype=dt)
+        m.compute_dtype = dt
+
+    def clip():
+        emb = pipe.image_encoder(inp["clip_pixels"].to(dt)).image_embeds
+        return pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], emb, inp["latents"], a.ddim_steps, a.guidance)
+
+    clip()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    clip()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = forward_output(pipe, dev, dt, a.size)
+    rel = float((out.float() - fp16_forward_out.float()).norm() / fp16_forward_out.float().norm())
+    return {"value": a.frames / el, "unit": "frames/s", "ms_per_step": el * 1e3, "steps": 1, "forward_rel_l2_vs_fp16": rel}
+
+
+def forward_output(pipe, dev, dtype, size):
+    """One denoising forward (CFG batch of 2 x 24 frames, banks installed) on fixed seeded inputs -> fp32 tokens."""
+    from mimo_amd.modules import Ctx, EarlyExit
+    from mimo_amd.unet import ReferenceAttentionControl
+    h = size // 8
+    unet, refu = pipe.denoising_unet, pipe.reference_unet
+    g = torch.Generator(device="cpu").manual_seed(7)
+    writer = ReferenceAttentionControl(refu, mode="write", do_classifier_free_guidance=True)
+    reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=True)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)]).to(dev)
+    rctx = Ctx(dtype, 1, 1)
+    rctx.stop_after = writer.last_block()
+    try:
+        refu.run_tokens(torch.randn(1, h, h, 8, generator=g).to(dev).to(dtype), 0, ehs[1:], 1, 1, None, rctx)
+    except EarlyExit:
+        pass
+    reader.update(writer)
+    x = torch.randn(48, h, h, 8, generator=g).to(dev).to(dtype)
+    pose = torch.randn(48, h, h, 320, generator=g).to(dev)
+    out = unet.run_tokens(x, 499, ehs, 2, 24, pose).clone()
+    reader.clear()
+    writer.clear()
+    return out
 
 
 def main():
@@ -204,6 +281,7 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="replay the denoising forward as a captured hipGraph "
                     "(measured neutral: the launch queue never runs dry, so eager launches are the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 sub-record (one extra clip + one forward)")
     ap.add_argument("--cpu-baseline-only", type=float, default=0.0, help=argparse.SUPPRESS)  # child mode: clip FLOPs
     a = ap.parse_args()
     if a.cpu_baseline_only > 0:
@@ -230,12 +308,17 @@ def main():
     pipe.use_graphs = a.graphs and not pipe.shard_windows
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
 
+    host_video = torch.empty((1, 3, frames, a.size, a.size), dtype=torch.float32, pin_memory=True)
+
     def clip():
-        # the whole __call__ body on device: CLIP image embedding, VAE encodes, pose guider, reference UNet,
-        # the denoising loop, VAE decode (pipeline_pose2vid_long_edit_bkfill_roiclip.py:379-578)
+        # the whole __call__ body: CLIP image embedding, VAE encodes, pose guider, reference UNet, the denoising loop,
+        # VAE decode (pipeline_pose2vid_long_edit_bkfill_roiclip.py:379-578), and the copy of the video tensor to the
+        # host (:125 `.cpu()`; SURVEY 8d: "from inputs on device to video tensor on host")
         emb = pipe.image_encoder(inp["clip_pixels"].to(dtype)).image_embeds
-        return pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], emb,
-                                inp["latents"], a.ddim_steps, a.guidance)
+        video = pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], emb,
+                                 inp["latents"], a.ddim_steps, a.guidance)
+        host_video.copy_(video, non_blocking=True)
+        return video
 
     def barrier():
         if world > 1:
@@ -273,10 +356,13 @@ def main():
             "metric": f"denoised frames/sec ({a.size}x{a.size}, {a.frames}f clip, {a.ddim_steps} DDIM steps)", "value": total_frames / (elapsed / a.steps),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {a.size}x{a.size}, {a.frames}-frame clip per GPU, {a.ddim_steps} DDIM steps, "
-                                   f"CFG {a.guidance}, CLIP image encoder + reference_unet + pose_guider + VAE enc/dec inside the timed region; "
-                                   + ("one long clip, (window x CFG-half) units sharded, all_gather per step" if a.shard_windows
-                                      else "independent clip per GPU, no collective"),
+            "config": {"workload": (f"BASELINE configs[3]: ONE {a.size}x{a.size} clip of {frames} frames sharded {a.frames} f/GPU over {world} GPUs "
+                                    f"({len(range(0, frames, 20)) if frames > 24 else 1} context windows x 2 CFG halves dealt over the ranks, slot-wise "
+                                    f"RCCL all_gather per step), " if a.shard_windows else
+                                    f"BASELINE configs[{1 if a.size == 512 else 4}]: {a.size}x{a.size}, {a.frames}-frame clip per GPU, independent clip per GPU "
+                                    f"(no collective), ") +
+                                   f"{a.ddim_steps} DDIM steps, CFG {a.guidance}; CLIP image encoder + reference_unet + pose_guider + VAE enc/dec + "
+                                   f"the device-to-host copy of the video inside the timed region",
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),
                        "kernel_launches_per_clip": clip_launches,
                        "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs)},
@@ -284,7 +370,8 @@ def main():
             # its launches in one denoising forward / the sum of their HIP-event durations
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel", "achieved": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gk["flops"] / (gk["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS,
-                         "traffic": pmc_traffic("gemm_kernel"), "launches_per_forward": gk["launches"], "avg_launch_us": gk["ms"] * 1e3 / gk["launches"],
+                         "traffic": pmc_traffic("gemm_kernel"), "algorithmic_bytes_per_launch": gk["bytes"] / gk["launches"],
+                         "launches_per_forward": gk["launches"], "avg_launch_us": gk["ms"] * 1e3 / gk["launches"],
                          "algorithmic_tflop_per_forward": gk["flops"] / 1e12,
                          "attn_kernel": {"achieved": fam["attn_kernel"]["flops"] / (fam["attn_kernel"]["ms"] * 1e-3) / 1e12,
                                          "launches_per_forward": fam["attn_kernel"]["launches"],
@@ -292,16 +379,21 @@ def main():
                          "forward": {"ms": t_fwd * 1e3, "executed_tflop": fwd_flops / 1e12, "launches": fwd_launches,
                                      "achieved": fwd_flops / t_fwd / 1e12, "frac": fwd_flops / t_fwd / 1e12 / PEAK_TFLOPS}},
         }
+        if world == 1 and not a.no_bf16 and a.dtype == "fp16":
+            try:
+                out["bf16"] = bf16_record(pipe, dev, inp, a, forward_output(pipe, dev, dtype, a.size))
+            except Exception as e:  # informational sub-record: never lose the headline line
+                out["bf16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             import subprocess
             try:  # child process with a hard wall-clock bound: the baseline is informational, never lose the GPU line
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
                                     str(float(clip_flops or fwd_flops * a.ddim_steps)), "--frames", str(a.frames)],
-                                   capture_output=True, text=True, timeout=150, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+                                   capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
                 out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": min(os.cpu_count(), 32), "kind": "port",
-                                       "sample": f"not measured within 150 s: {type(e).__name__}"}
+                                       "sample": f"not measured within 240 s: {type(e).__name__}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 // ------------------------------------------------------------------------------------
 // attn40_kernel: the d = 40 level (N = 4096 at 512x512: the largest single kernel of the denoising forward),
 // Q pre-multiplied by softmax_scale * log2(e).  Differences from attn_kernel, each aimed at a measured limit of it
-// (profiles/r1_pmc_sq_counters_attn_and_conv.txt: MFMA pipe 48 % busy, 11 VALU-class instructions per MFMA):
-//   * a wave owns 64 queries (two 32-query blocks A, B), a block 256: every K / V^T fragment read from LDS feeds
-//     twice the MFMAs, and the K/V stream per FLOP (L2 -> LDS) is half that of a 128-query block;
+// (profiles/r1_pmc_sq_counters_attn_and_conv.txt, profiles/r2_attn40_*.txt):
+//   * a wave owns 64 queries (two 32-query blocks A, B), a block 256: every K / V fragment read from LDS feeds twice
+//     the MFMAs, and the K/V stream per FLOP is half that of a 128-query block (fabric-side fetch 3.0 GB -> 0.7 GB);
 //   * P.V runs on 16x16x32 MFMAs: O^T is 48 rows (40 + the ones-row that yields the softmax denominators), not 64.
 //     The 32x32 S^T accumulators become 16x16x32 B operands with one v_permlane16_swap per packed register pair
 //     (odd 16-lane rows of one register <-> even rows of the other), no LDS round trip;
@@ -364,32 +364,31 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 //     attn_kernel<40, FAST>), and instead of a running max the packed P words are OR-ed together — bit 14 of a half
 //     is set exactly when p >= 2, i.e. a score overshot the reference (which is kept 3 above the running max).
 //     Only then (and on the first tile) S is recomputed and re-referenced: exact softmax arithmetic either way;
-//   * program order per KV tile: QK^T(A) | QK^T(B) with softmax(A) in its shadow | P.V(A) with softmax(B) in its
-//     shadow | P.V(B) with the next tile's V^T staging in its shadow;
-//   * K tiles go global -> LDS by DMA (row pitch 80 B is bank-conflict-free for the fragment reads as it is), the
-//     bias column of the reference-max trick is a constant 16-byte LDS slot; V^T is staged as packed kv pairs
-//     (8 ds_write_b32 per thread instead of 16 ds_write_b16) in a kv order that makes a fragment ONE ds_read_b128;
+//   * BOTH K and V tiles go global -> LDS by DMA, row-major as they lie in memory (row pitch 80 B), into a 3-deep
+//     ring: the loads of tile t+2 are issued before tile t is consumed and waited for with a COUNTED vmcnt (no VGPR
+//     staging, no compiler-inserted vmcnt(0) drain).  The ablation that removes all loop traffic runs 27 % faster than
+//     the 2-buffer form did: the loop was bound by the latency of loads with one tile of slack, not by bandwidth
+//     (L2 hit rate 95 %).  V^T fragments come out of the row-major V tile with ds_read_b64_tr_b16 (hardware
+//     transpose: lane (g, i) receives V[kv0 + j][d0 + i], j < 4); K column 40 (the bias column of the reference-max
+//     trick) and V^T rows 40..47 (ones-row + padding) are constant LDS slots the fragment addresses point at;
 //   * 1-D grid, XCD-aware: consecutive logical blocks (same batch row and head = same K/V) run on one XCD and hit in
 //     its L2; cond (two KV segments) and uncond batch rows alternate so every XCD gets the same work.
 // ------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tile's K / V):
+// ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tiles' K / V):
 // the compute-only time of the loop, for telling a memory-latency bound from an issue bound
-template <int DT, int ORDER, int ABL = 0>
+template <int DT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
-  constexpr int KROWB = 80;                 // K tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
-  constexpr int KBUF = KV_TILE * KROWB;     // 5120 B per K buffer
-  constexpr int VROWB = 160;                // V^T row pitch in bytes: 64 kv halfs + pad (conflict-free ds_read_b128)
-  constexpr int VROWS = 48;                 // d rows: 40 + row 40 = ones (denominator) + 7 zero rows
-  constexpr int VBUF = VROWS * VROWB;       // 7680 B per V^T buffer
-  constexpr int CONST_OFF = 2 * KBUF;       // 16-byte slot (1, 0, ..., 0): K columns 40..47 of every row
-  constexpr int V_OFF = CONST_OFF + 64;
-  constexpr int DUMMY_OFF = V_OFF + 2 * VBUF;  // write-only scratch: threads without a staging item store here (branch-free)
+  constexpr int NB = 3;                     // ring depth (tiles t, t+1, t+2)
+  constexpr int ROWB = 80;                  // K / V tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
+  constexpr int TILEB = KV_TILE * ROWB;     // 5120 B per tile
+  constexpr int K_OFF = 0, V_OFF = NB * TILEB;
+  constexpr int CONST_OFF = 2 * NB * TILEB; // [0,16): halfs (1, 0 x 7) = K columns 40..47; [16,24): (1,0,0,0) = V^T row 40 of 4 kv; [24,32): zeros
   constexpr float HEAD = 3.f;               // the reference sits HEAD above the running max: p <= 2^-3 until it is overshot
   // ONE LDS object (a second one would make hipcc drain vmcnt before every fragment read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DUMMY_OFF + 7 * VROWB + 256];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CONST_OFF + 64];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,15 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     b = (b & 1) ? (b >> 1) : a.seg2_first_batch + (b >> 1);
   const int q0 = (int)qblk * 256 + wave * 64;
 
-  // ---- LDS init: V^T buffers zero, row 40 ones; the constant K slot ----
-  for (int i = tid; i < 2 * VBUF / 4; i += 256) reinterpret_cast<uint32_t*>(smem + V_OFF)[i] = 0u;
-  if (tid < 4) reinterpret_cast<uint32_t*>(smem + CONST_OFF)[tid] = tid == 0 ? (uint32_t)HT<DT>::from_f(1.0f) : 0u;
-  __syncthreads();
-  {
-    const uint32_t one2 = (uint32_t)HT<DT>::from_f(1.0f) * 0x10001u;
-    for (int i = tid; i < 2 * (VROWB / 4); i += 256)
-      reinterpret_cast<uint32_t*>(smem + V_OFF + (i / (VROWB / 4)) * VBUF + D * VROWB)[i % (VROWB / 4)] = one2;
-  }
+  if (tid < 8) reinterpret_cast<uint32_t*>(smem + CONST_OFF)[tid] = (tid == 0 || tid == 4) ? (uint32_t)HT<DT>::from_f(1.0f) : 0u;
 
   // ---- Q^T fragments (B operand of the 32x32x16 MFMA): lane (h2, q = li) holds Q[q][16 s + 8 h2 .. +8] ----
   uint4 qf[2][3];
@@ -434,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the Q loads are the only compiler-tracked loads: the DMA counts below start at zero
 
   // O^T accumulators, 16x16 tiles: ot[x][dt][j]: lane (g, n) holds O^T[d = 16 dt + 4 g + r][q = 32 x + 16 j + n]
   f32x4 ot[2][3][2];
@@ -451,7 +443,8 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   const uint16_t* kb0 = a.k + (int64_t)b * a.Nk * a.ldk;
   const uint16_t* vb0 = a.v + (int64_t)b * a.Nk * a.ldv;
 
-  // ---- K tile DMA: 320 16-byte chunks = 5 wave-DMAs; wave w issues DMA w, wave 0 also DMA 4 ----
+  // ---- tile DMA: K and V are 320 16-byte chunks each = 5 + 5 wave-DMAs per tile; wave w issues DMAs w, w + 4 and
+  // (w < 2) w + 8 of the list [K0..K4, V0..V4]: 3 | 3 | 2 | 2 per wave, the count the vmcnt waits below rely on ----
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t p64 = reinterpret_cast<uint64_t>(ptr);
     i32x4 r;
@@ -459,78 +452,54 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     return r;
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0];
-  int krow_[2];
-  unsigned kcol_[2];
+  int drow[3];       // tile row of this lane's chunk in DMA jj
+  unsigned dcol[3];  // byte offset of the chunk inside a token row
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int c = 64 * (jj == 0 ? wave : 4) + lane;
-    krow_[jj] = c / 5;
-    kcol_[jj] = (unsigned)((head * D + (c - krow_[jj] * 5) * 8) * 2);
+  for (int jj = 0; jj < 3; ++jj) {
+    const int j = wave + 4 * jj;                // DMA index 0..9 (jj = 2 exists for waves 0, 1 only)
+    const int c = 64 * (j >= 5 ? j - 5 : j) + lane;
+    drow[jj] = c / 5;
+    dcol[jj] = (unsigned)((head * D + (c - drow[jj] * 5) * 8) * 2);
   }
-  auto dma_k = [&](int t, int buf) {
+  auto issue_tile = [&](int t, int buf) {
     const bool s2 = t >= T0;
-    const uint16_t* kb = s2 ? a.k2 : kb0;
-    const unsigned ldkb = (unsigned)((s2 ? a.ldk2 : a.ldk) * 2);
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
-    const i32x4 rk = make_rsrc(kb, (unsigned)((int64_t)nk * ldkb));
+    const unsigned ldkb = (unsigned)((s2 ? a.ldk2 : a.ldk) * 2), ldvb = (unsigned)((s2 ? a.ldv2 : a.ldv) * 2);
+    const i32x4 rk = make_rsrc(s2 ? a.k2 : kb0, (unsigned)((int64_t)nk * ldkb));
+    const i32x4 rv = make_rsrc(s2 ? a.v2 : vb0, (unsigned)((int64_t)nk * ldvb));
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      if (jj == 1 && wave != 0) break;  // wave-uniform
-      const bool ok = kv0 + krow_[jj] < nk;
-      const unsigned off = ok ? (unsigned)(kv0 + krow_[jj]) * ldkb + kcol_[jj] : 0xFFFFFFF0u;
-      const unsigned dst = smem_base + (unsigned)(buf * KBUF + 1024 * (jj == 0 ? wave : 4));
+    for (int jj = 0; jj < 3; ++jj) {
+      if (jj == 2 && wave >= 2) break;  // wave-uniform
+      const int j = wave + 4 * jj;
+      const bool isv = j >= 5;          // wave-uniform
+      const bool ok = kv0 + drow[jj] < nk;
+      const unsigned off = ok ? (unsigned)(kv0 + drow[jj]) * (isv ? ldvb : ldkb) + dcol[jj] : 0xFFFFFFF0u;
+      const unsigned dst = smem_base + (unsigned)((isv ? V_OFF : K_OFF) + buf * TILEB + 1024 * (isv ? j - 5 : j));
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off), "s"(rk), "s"(dst) : "memory");
+                   : "=&s"(keep) : "v"(off), "s"(isv ? rv : rk), "s"(dst) : "memory");
     }
+  };
+  // wait until only this wave's DMAs of the NEWEST tile (3 or 2 per wave) may still be in flight
+  auto wait_all_but_newest = [&]() {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
 
-  // ---- V staging: thread (kv pair p, 8-d chunk c) for tid < 160; registers -> packed V^T ----
-  const bool vlive = tid < 160;
-  const int vp = tid & 31, vc = tid >> 5;
-  u32x4 vreg[2];
-  // position of kv (within its 32-kv sub-tile) in the V^T row: the 8 k-slots of lane group g' are contiguous,
-  // g' = (quad >> 2) + 2 (quad & 1), slot = 4 ((quad >> 1) & 1) + (kv & 3)   [quad = kv_local >> 2]
-  unsigned vlds;  // byte offset of this thread's word inside a V^T buffer, row 8 c
-  {
-    const int kv = 2 * vp, u = kv >> 5, kl = kv & 31, quad = kl >> 2;
-    const int gg = (quad >> 2) + 2 * (quad & 1), slot = 4 * ((quad >> 1) & 1) + (kl & 3);
-    vlds = (unsigned)(V_OFF + (8 * vc) * VROWB + (32 * u + 8 * gg + slot) * 2);
-  }
-  const unsigned vlds0 = vlive ? vlds : (unsigned)(DUMMY_OFF + 4 * lane);
-  const unsigned vlds1 = vlive ? vlds + VBUF : (unsigned)(DUMMY_OFF + 4 * lane);
-  auto issue_v = [&](int t) {
-    const bool s2 = t >= T0;
-    const uint16_t* vb = s2 ? a.v2 : vb0;
-    const unsigned ldvb = (unsigned)((s2 ? a.ldv2 : a.ldv) * 2);
-    const int nk = s2 ? a.Nk2 : a.Nk;
-    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)nk * ldvb), 0x00020000);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int kv = kv0 + 2 * vp + r;
-      const bool ok = vlive & (kv < nk);
-      vreg[r] = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (unsigned)kv * ldvb + (unsigned)((head * D + vc * 8) * 2) : 0xFFFFFFF0u, 0, 0);
-    }
-  };
-  auto stage_v = [&](int buf) {  // branch-free, so that it schedules into the shadow of the P.V MFMAs
-    unsigned char* vt = smem + (buf ? vlds1 : vlds0);
-    const uint32_t w0[4] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w};
-    const uint32_t w1[4] = {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<uint32_t*>(vt + (2 * e) * VROWB) = __builtin_amdgcn_perm(w1[e], w0[e], 0x05040100u);
-      *reinterpret_cast<uint32_t*>(vt + (2 * e + 1) * VROWB) = __builtin_amdgcn_perm(w1[e], w0[e], 0x07060302u);
-    }
-  };
-
-  // per-lane fragment addresses inside buffer 0 (loop-invariant); lanes h2 = 1 read K columns 40..47 from the
-  // constant slot, whose address does not move with the buffer
-  const unsigned kaddr = (unsigned)(li * KROWB + 16 * h2);            // + 32 u rows + 32 s bytes
-  const unsigned kaddr2_0 = h2 ? (unsigned)CONST_OFF : kaddr + 64;     // k-step 2, buffer 0
-  const unsigned kaddr2_d = h2 ? 0u : (unsigned)KBUF;                  // ... its step to buffer 1
-  const unsigned vaddr = (unsigned)(V_OFF + i16 * VROWB + 16 * g);    // + 16 dt rows + 64 u bytes
+  // per-lane fragment addresses inside ring slot 0 (loop-invariant).  K (A operand, 32x32x16): row 32 u + li, bytes
+  // 32 s + 16 h2; lanes h2 = 1 read columns 40..47 of k-step 2 from the constant slot, whose address does not move.
+  const unsigned kaddr = (unsigned)(K_OFF + li * ROWB + 16 * h2);
+  const unsigned kaddr2_0 = h2 ? (unsigned)CONST_OFF : kaddr + 64;
+  const unsigned kaddr2_d = h2 ? 0u : (unsigned)TILEB;
+  // V^T (A operand, 16x16x32) by transposed read: lane m = i16 of group g supplies the address of 4 consecutive d of kv row
+  // {0, 16, 4, 20}[g] + (m >> 2), d = 16 dt + 4 (m & 3) ..; the hardware hands lane i the column d = 16 dt + i of those
+  // 4 kv rows.  For dt = 2 the chunks m & 3 = 2, 3 (d = 40..47) are the constant ones-row / zero slots.
+  const int kvb = 16 * (g & 1) + 4 * (g >> 1);
+  const unsigned vaddr = smem_base + (unsigned)(V_OFF + (kvb + (i16 >> 2)) * ROWB + 8 * (i16 & 3));
+  const bool vconst = (i16 & 3) >= 2;
+  const unsigned vaddr2 = vconst ? smem_base + (unsigned)(CONST_OFF + 16 + 8 * ((i16 & 3) - 2)) : vaddr + 64;
+  const unsigned vstep2 = vconst ? 0u : 1u;
 
   f32x16 zero16;
 #pragma unroll
@@ -603,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   // packed P words of the 32x32 layout -> B operands of the 16x16x32 MFMA.  w[k] (k < 4) holds kv {0..3, 8..11} + 4 h2
   // and w[4 + k] kv {16..19, 24..27} + 4 h2 of query li.  Swapping the odd 16-lane rows of w[k] with the even rows of
   // w[4 + k] leaves in w[k] the fragment of query tile 0 (q = i16) and in w[4 + k] that of query tile 1 (q = 16 + i16);
-  // lane group g then holds the kv set {0, 16, 4, 20}[g] + {0..3, 8..11} — the order V^T is stored in.
+  // lane group g then holds the kv set {0, 16, 4, 20}[g] + {0..3, 8..11} — the rows the V^T reads above gather.
   auto to_frag = [&](uint32_t (&w)[2][8], uint4 (&pf)[2][2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -617,98 +586,95 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
       pf[u][1] = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
     }
   };
-  // O^T(x) += V^T.P^T(x): d tiles {0..15, 16..31, 32..47}, two k-steps of 32 kv
-  auto pv = [&](const unsigned char* vbuf, int x, const uint4 (&pf)[2][2]) {
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(vbuf + dt * 16 * VROWB + 64 * u);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ot[x][dt][j] = HT<DT>::mfma16(vf, pf[u][j], ot[x][dt][j]);
-      }
-  };
 
-  // ---- one KV tile; CUR (the LDS buffer pair it reads) is a compile-time constant ----
+  // ---- one KV tile; CUR (the ring slot it reads) is a compile-time constant ----
   auto tile = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
-    if (t + 1 < T && ABL != 1) dma_k(t + 1, CUR ^ 1);  // buffer CUR^1 was last read in iteration t-1 (barrier passed)
+    constexpr int RD = ABL == 1 ? 0 : CUR;   // (ablation: every tile reads slot 0)
+    if (t + 2 < T && ABL != 1) issue_tile(t + 2, (CUR + 2) % NB);  // that slot was last read in iteration t-1 (barrier passed)
     const bool s2 = t >= T0;
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
     const bool special = (t == 0) | (kv0 + KV_TILE > nk);  // wave-uniform: first / ragged tiles take the slow path
-    const unsigned char* kbuf = smem + (ABL == 1 ? 0 : CUR) * KBUF;
-    const unsigned char* vbuf = smem + CUR * VBUF + vaddr;
+    const unsigned char* kbuf = smem + RD * TILEB;
 
     uint4 kf[2][3];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB);
-      kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * KROWB + 32);
-      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + (ABL == 1 ? 0 : CUR) * kaddr2_d + (h2 ? 0 : u * 32 * KROWB));
+      kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB);
+      kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB + 32);
+      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + RD * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
     }
     f32x16 sa[2], sb[2];
     uint32_t wa[2][8], wb[2][8];
     uint4 pa[2][2], pb[2][2];
-    if (ORDER == 0 || ORDER == 2) {
-      // QK^T(A) | QK^T(B) + softmax(A) | P.V(A) + softmax(B) | P.V(B) + staging
-      qk(kf, 0, sa);
-      qk(kf, 1, sb);
-      const uint32_t ora = exp_pack(sa, wa);
-      if (ORDER == 2) {  // pin the interleave: QK^T(A) back to back, then one QK^T(B) MFMA per 9 softmax(A) instructions
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    qk(kf, 0, sa);
+    qk(kf, 1, sb);
+    // V^T fragments of the whole tile: 12 transposed reads issued now, waited for after the softmax (the compiler does
+    // not track asm loads: the wait statement below names every destination)
+    uint2 vlo[3][2], vhi[3][2];
+    {
+      const unsigned va2 = vaddr2 + (unsigned)(RD * TILEB) * vstep2;
+#define MIMO_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
-        }
+      for (int u = 0; u < 2; ++u) {
+        MIMO_TR(vlo[0][u], vaddr, RD * TILEB + 32 * u * ROWB);
+        MIMO_TR(vhi[0][u], vaddr, RD * TILEB + (32 * u + 8) * ROWB);
+        MIMO_TR(vlo[1][u], vaddr, RD * TILEB + 32 * u * ROWB + 32);
+        MIMO_TR(vhi[1][u], vaddr, RD * TILEB + (32 * u + 8) * ROWB + 32);
       }
-      if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
-      to_frag(wa, pa);
-      const uint32_t orb = exp_pack(sb, wb);
-      pv(vbuf, 0, pa);
-      if (ORDER == 2) {  // one P.V(A) MFMA per 5 softmax(B) instructions
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
-        }
+      // dt = 2: lanes of the constant chunks must not move with u / hi: their offsets are applied through vstep2
+      {
+        const unsigned a00 = va2, a01 = va2 + (8 * ROWB) * vstep2, a10 = va2 + (32 * ROWB) * vstep2, a11 = va2 + (40 * ROWB) * vstep2;
+        MIMO_TR(vlo[2][0], a00, 0);
+        MIMO_TR(vhi[2][0], a01, 0);
+        MIMO_TR(vlo[2][1], a10, 0);
+        MIMO_TR(vhi[2][1], a11, 0);
       }
-      if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
-      to_frag(wb, pb);
-    } else {
-      // plain order: both QK^T, both softmaxes, both P.V
-      qk(kf, 0, sa);
-      qk(kf, 1, sb);
-      const uint32_t ora = exp_pack(sa, wa);
-      const uint32_t orb = exp_pack(sb, wb);
-      if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
-      if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
-      to_frag(wa, pa);
-      to_frag(wb, pb);
-      pv(vbuf, 0, pa);
+#undef MIMO_TR
     }
-    if (t + 1 < T) stage_v(CUR ^ 1);                      // tile t+1 (in registers) -> the other V^T buffer
-    pv(vbuf, 1, pb);
+    const uint32_t ora = exp_pack(sa, wa);
+    const uint32_t orb = exp_pack(sb, wb);
+    if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
+    if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
+    to_frag(wa, pa);
+    to_frag(wb, pb);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vlo[2][0]), "+v"(vlo[2][1]),
+                   "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1]), "+v"(vhi[2][0]), "+v"(vhi[2][1])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // no MFMA may be hoisted above the wait (cdna_hip_programming.md rule 18)
+    // ---- O^T += V^T.P^T: d tiles {0..15, 16..31, 32..47}, two k-steps of 32 kv; every V^T fragment feeds 4 query tiles ----
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 vf = make_uint4(vlo[dt][u].x, vlo[dt][u].y, vhi[dt][u].x, vhi[dt][u].y);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          ot[0][dt][j] = HT<DT>::mfma16(vf, pa[u][j], ot[0][dt][j]);
+          ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
+        }
+      }
     if (t + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's K(t+1) DMA has landed
-      if (t + 2 < T && ABL != 1) issue_v(t + 2);
-      __syncthreads();                                    // publishes tile t+1; every wave is done with buffers CUR
+      // tile t+1 (issued one iteration ago) has to be in LDS; tile t+2 (issued above) may stay in flight
+      if (t + 2 < T && ABL != 1) wait_all_but_newest();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // publishes tile t+1; every wave is done reading slot CUR
     }
   };
 
-  // ---- pipeline: K(t+1) DMA and V(t+1) staging + V(t+2) loads run under the MFMAs of tile t; ONE barrier per tile ----
-  dma_k(0, 0);
-  issue_v(0);
-  __syncthreads();  // orders the LDS init
-  stage_v(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (T > 1) issue_v(1);
-  __syncthreads();
+  // ---- pipeline: two tiles in flight ahead of the one being consumed; ONE barrier per tile ----
+  issue_tile(0, 0);
+  if (T > 1) issue_tile(1, 1);
+  if (T > 1) wait_all_but_newest();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // tile 0 and the constant slots are visible
 
-  for (int t = 0; t < T; t += 2) {
+  for (int t = 0; t < T; t += 3) {
     tile(IC2<0>{}, t);
     if (t + 1 < T) tile(IC2<1>{}, t + 1);
+    if (t + 2 < T) tile(IC2<2>{}, t + 2);
   }
 
   // ---- epilogue: denominators from the ones-row (d = 40: tile 2, row 8 -> lane group 2, register 0) ----
@@ -882,16 +848,13 @@ static inline bool attn40_legacy() { return tune_env("MIMO_ATTN40_LEGACY", 0) !=
 template <int DT>
 static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(((a.Nq + 255) / 256) * a.heads * a.B));
-  const int order = tune_env("MIMO_ATTN40_ORDER", 1);
 #ifdef MIMO_TUNE
   if (tune_env("MIMO_ATTN40_ABLATE", 0) == 1) {
-    hipLaunchKernelGGL((attn40_kernel<DT, 1, 1>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn40_kernel<DT, 1>), grid, dim3(256), 0, st, a);
     return;
   }
 #endif
-  if (order == 1) hipLaunchKernelGGL((attn40_kernel<DT, 1>), grid, dim3(256), 0, st, a);
-  else if (order == 2) hipLaunchKernelGGL((attn40_kernel<DT, 2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn40_kernel<DT, 0>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn40_kernel<DT, 0>), grid, dim3(256), 0, st, a);
 }
 
 extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,

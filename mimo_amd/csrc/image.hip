@@ -19,7 +19,9 @@
 //     width (no FMA contraction), so the uint8 result equals the reference's.
 #include "common.cuh"
 
-// numpy rounds every multiply and add separately: no FMA contraction anywhere in this file
+// numpy rounds every multiply and add separately: no FMA contraction anywhere in this file.  The arithmetic below is
+// written with plain operators ON PURPOSE: the pragma governs expressions in this file, whereas the __fmul_rn / __dadd_rn
+// helpers are inline functions compiled under the headers' own (contracting) mode and fuse again once inlined.
 #pragma clang fp contract(off)
 
 namespace {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void resample_pass_kernel(const ResampleArgs a
       for (int j = 0; j < count; ++j) {
         const int64_t idx = base + j * step + c * a.sc;
         int p;
-        if (a.src_f32) p = (int)(uint8_t)(int)__fmul_rn(((const float*)a.src)[idx], 255.0f);
+        if (a.src_f32) p = (int)(uint8_t)(int)(((const float*)a.src)[idx] * 255.0f);
         else p = ((const uint8_t*)a.src)[idx];
         ss += p * k[j];
       }
@@ -72,8 +74,8 @@ __global__ __launch_bounds__(256) void u8_to_tokens_kernel(const uint8_t* src, i
     for (int c = 0; c < cpad; ++c) {
       float v = 0.f;
       if (c < C) {
-        v = __fdiv_rn((float)src[i * C + c], 255.0f);
-        if (two_x_minus_1) v = __fsub_rn(__fmul_rn(2.0f, v), 1.0f);
+        v = (float)src[i * C + c] / 255.0f;
+        if (two_x_minus_1) v = 2.0f * v - 1.0f;
       }
       dst[i * cpad + c] = HT<DT>::from_f(v);
     }
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void u8_to_planar_kernel(const uint8_t* src, i
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t img = i / HW, p = i - img * HW;
     for (int c = 0; c < C; ++c)
-      dst[(img * C + c) * HW + p] = __fdiv_rn(__fsub_rn(__fmul_rn((float)src[i * C + c], rescale), mean[c]), stdv[c]);
+      dst[(img * C + c) * HW + p] = ((float)src[i * C + c] * rescale - mean[c]) / stdv[c];
   }
 }
 
@@ -115,20 +117,20 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeArgs a) {
     const bool in_crop = (cy >= 0) & (cy < ch) & (cx >= 0) & (cx < cw);
     const bool in_mask = (cy >= 0) & (cy < a.mh) & (cx >= 0) & (cx < a.mw);
     const float m = in_mask ? a.mask[(int64_t)cy * a.mw + cx] : 0.f;
-    const float one_m = __fsub_rn(1.0f, m);
+    const float one_m = 1.0f - m;
     double o = 0.0, one_o = 1.0;
     if (a.occ) {
-      o = __ddiv_rn((double)a.occ[i * 3], 255.0);
-      one_o = __dsub_rn(1.0, o);
+      o = (double)a.occ[i * 3] / 255.0;
+      one_o = 1.0 - o;
     }
     for (int c = 0; c < 3; ++c) {
       const float canvas = in_crop ? (float)a.crop[((int64_t)(cy + a.top) * a.pad_w + (cx + a.left)) * 3 + c] : 255.0f;
       // res_image * mask_full[..., None] + bk_image * (1 - mask_full[..., None]): float32
-      const float r32 = __fadd_rn(__fmul_rn(canvas, m), __fmul_rn((float)a.bk[i * 3 + c], one_m));
+      const float r32 = canvas * m + (float)a.bk[i * 3 + c] * one_m;
       double r;
       bool r_is_f64 = false;
       if (a.occ) {  // res_image * (1 - occ) + vid_image * occ: float64
-        r = __dadd_rn(__dmul_rn((double)r32, one_o), __dmul_rn((double)a.vid[i * 3 + c], o));
+        r = (double)r32 * one_o + (double)a.vid[i * 3 + c] * o;
         r_is_f64 = true;
       } else {
         r = (double)r32;
@@ -137,9 +139,9 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeArgs a) {
       if (a.prev) {
         // res_images[i] * (1 - factor) + res_image * factor: the uint8 array times a Python float is float64; a float32
         // res_image times a Python float stays float32 (the scalar is cast), a float64 one float64
-        const double pterm = __dmul_rn((double)a.prev[i * 3 + c], __dsub_rn(1.0, a.factor));
-        const double rterm = r_is_f64 ? __dmul_rn(r, a.factor) : (double)__fmul_rn(r32, (float)a.factor);
-        q = (uint8_t)(int)__dadd_rn(pterm, rterm);
+        const double pterm = (double)a.prev[i * 3 + c] * (1.0 - a.factor);
+        const double rterm = r_is_f64 ? r * a.factor : (double)(r32 * (float)a.factor);
+        q = (uint8_t)(int)(pterm + rterm);
       } else {
         q = r_is_f64 ? (uint8_t)(int)r : (uint8_t)(int)r32;
       }

@@ -29,9 +29,14 @@ def _count(flops):
         COUNTER["launches"] += 1
 
 
+def _nbytes(*tensors):
+    """Algorithmic HBM bytes of a launch: every operand read once, every result written once."""
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
+
 class _Bracket:
-    def __init__(self, family, flops):
-        self.family, self.flops = family, flops
+    def __init__(self, family, flops, nbytes=0):
+        self.family, self.flops, self.nbytes = family, flops, nbytes
 
     def __enter__(self):
         if EVENTS is not None:
@@ -42,7 +47,7 @@ class _Bracket:
         if EVENTS is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            EVENTS.append((self.family, self.e0, e1, self.flops))
+            EVENTS.append((self.family, self.e0, e1, self.flops, self.nbytes))
         return False
 
 
@@ -105,13 +110,17 @@ def _workspace(device):
 # the fp32 [M/32, 2, N] tensor to its output as `_cs`; group_norm() consumes it instead of re-reading the tensor.
 # The decision depends on the IMAGE size only, never on the batch: a frame's statistics must be computed the same way
 # however many frames share the launch (the sharded long-clip mode reproduces the single-GPU bits).  Images below
-# COLSTATS_MIN_HW pixels keep split-K available instead (the 8x8 level: one more pass over 16 MB is the cheaper way).
+# COLSTATS_MIN_HW pixels keep split-K available instead (the 8x8 level: one more pass over 16 MB is the cheaper way);
+# above COLSTATS_MAX_HW the statistics epilogue costs the producer more than the separate statistics pass it saves
+# (measured at 64x64 x 320: +34 us on the convolution vs 25 us for the pass, which reads the just-written tensor from
+# the Infinity Cache; at 32x32 x 640 +9 us vs 36 us, profiles/r2_microbench_fused.txt).
 COLSTATS_MIN_HW = 256
+COLSTATS_MAX_HW = 1024
 
 
 def _want_colstats(rows_per_image, M):
     hw = int(rows_per_image or 0)
-    return hw >= COLSTATS_MIN_HW and hw % 32 == 0 and M % hw == 0
+    return COLSTATS_MIN_HW <= hw <= COLSTATS_MAX_HW and hw % 32 == 0 and M % hw == 0
 
 
 def with_stats(t, cs):
@@ -190,7 +199,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     if fuse_ln:
         ln_out = torch.empty((M, N), device=a.device, dtype=a.dtype)
     _count(2 * M * N * K)
-    with _Bracket("gemm_kernel", 2 * M * N * K):
+    with _Bracket("gemm_kernel", 2 * M * N * K, M * K * a.element_size() + _nbytes(w, out, residual, ln_out, cs)):
         ws = _workspace(a.device)
         if cs is None and ln_out is None:
             L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
@@ -251,7 +260,7 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
         cs = torch.empty((M // 32, 2, cout), device=x.device, dtype=torch.float32)
     fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
     _count(fl)
-    with _Bracket("gemm_kernel", fl):
+    with _Bracket("gemm_kernel", fl, _nbytes(x, x2, w, out, residual, cs)):
         ws = _workspace(x.device)
         if cs is None:
             L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),
@@ -352,7 +361,7 @@ def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=Non
         scale = d ** -0.5
     fl = 4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2)
     _count(fl)
-    with _Bracket("attn_kernel", fl):
+    with _Bracket("attn_kernel", fl, (B * (Nq * 2 + Nk * 2) * C + (2 * Nk2 * C if Nk2 else 0)) * q.element_size()):
         L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
                v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
                seg2_first_batch, heads, d, float(scale), _stream())

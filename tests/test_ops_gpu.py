@@ -243,7 +243,7 @@ def test_layer_norm_and_pe(dev, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hw,C1,C2", [(32, 320, 0), (32, 640, 320), (16, 1280, 640), (64, 320, 320)])
+@pytest.mark.parametrize("hw,C1,C2", [(32, 320, 0), (32, 640, 320), (16, 1280, 640), (16, 320, 320)])
 def test_group_norm_from_epilogue_column_stats(dev, dtype, hw, C1, C2):
     """GroupNorm statistics merged from the column statistics that the PRODUCING conv / GEMM epilogue emitted
     (mimo_epilogue_ext.colstats -> mimo_group_norm_stats_cols) equal a pass over the tensor.  The virtual concat puts
