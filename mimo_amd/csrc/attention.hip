@@ -378,8 +378,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tiles' K / V):
 // the compute-only time of the loop, for telling a memory-latency bound from an issue bound
-template <int DT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
+// NW = waves per block (4 | 8): a block covers 64 NW queries.  The per-tile DMA work (10 instructions, ~100+ issue cycles
+// each inside a busy phase) is fixed per block, so 8 waves halve its cost per FLOP.
+template <int DT, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
   constexpr int NB = 3;                     // ring depth (tiles t, t+1, t+2)
   constexpr int ROWB = 80;                  // K / V tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   const int g = lane >> 4, i16 = lane & 15;   // 16x16 MFMA view: k-slot group g, row / column i16
 
   // ---- block -> (batch row, head, 256-query block); logical id L walks query blocks fastest ----
-  const unsigned nqb = (unsigned)((a.Nq + 255) / 256);
+  constexpr int QB = 64 * NW;
+  const unsigned nqb = (unsigned)((a.Nq + QB - 1) / QB);
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned qblk = L % nqb;
   const unsigned hb = L / nqb;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   int b = (int)(hb / (unsigned)a.heads);
   if (a.k2 && a.Nk2 > 0 && 2 * a.seg2_first_batch == a.B)  // alternate long (two-segment) and short batch rows
     b = (b & 1) ? (b >> 1) : a.seg2_first_batch + (b >> 1);
-  const int q0 = (int)qblk * 256 + wave * 64;
+  const int q0 = (int)qblk * QB + wave * 64;
 
   if (tid < 8) reinterpret_cast<uint32_t*>(smem + CONST_OFF)[tid] = (tid == 0 || tid == 4) ? (uint32_t)HT<DT>::from_f(1.0f) : 0u;
 
@@ -443,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   const uint16_t* kb0 = a.k + (int64_t)b * a.Nk * a.ldk;
   const uint16_t* vb0 = a.v + (int64_t)b * a.Nk * a.ldv;
 
-  // ---- tile DMA: K and V are 320 16-byte chunks each = 5 + 5 wave-DMAs per tile; wave w issues DMAs w, w + 4 and
-  // (w < 2) w + 8 of the list [K0..K4, V0..V4]: 3 | 3 | 2 | 2 per wave, the count the vmcnt waits below rely on ----
+  // ---- tile DMA: K and V are 320 16-byte chunks each = 5 + 5 wave-DMAs per tile; wave w issues DMAs w, w + NW, ... < 10 of
+  // the list [K0..K4, V0..V4]: 3 | 3 | 2 | 2 per wave (NW = 4), 2 | 2 | 1 x 6 (NW = 8): the counts the vmcnt waits rely on ----
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t p64 = reinterpret_cast<uint64_t>(ptr);
     i32x4 r;
@@ -452,11 +455,12 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     return r;
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0];
-  int drow[3];       // tile row of this lane's chunk in DMA jj
-  unsigned dcol[3];  // byte offset of the chunk inside a token row
+  constexpr int NJ = (10 + NW - 1) / NW;  // DMAs of the busiest wave
+  int drow[NJ];       // tile row of this lane's chunk in DMA jj
+  unsigned dcol[NJ];  // byte offset of the chunk inside a token row
 #pragma unroll
-  for (int jj = 0; jj < 3; ++jj) {
-    const int j = wave + 4 * jj;                // DMA index 0..9 (jj = 2 exists for waves 0, 1 only)
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = wave + NW * jj;                // DMA index 0..9 (the last jj exists for waves 0, 1 only)
     const int c = 64 * (j >= 5 ? j - 5 : j) + lane;
     drow[jj] = c / 5;
     dcol[jj] = (unsigned)((head * D + (c - drow[jj] * 5) * 8) * 2);
@@ -469,9 +473,9 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
     const i32x4 rk = make_rsrc(s2 ? a.k2 : kb0, (unsigned)((int64_t)nk * ldkb));
     const i32x4 rv = make_rsrc(s2 ? a.v2 : vb0, (unsigned)((int64_t)nk * ldvb));
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      if (jj == 2 && wave >= 2) break;  // wave-uniform
-      const int j = wave + 4 * jj;
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int j = wave + NW * jj;
+      if (j >= 10) break;  // wave-uniform
       const bool isv = j >= 5;          // wave-uniform
       const bool ok = kv0 + drow[jj] < nk;
       const unsigned off = ok ? (unsigned)(kv0 + drow[jj]) * (isv ? ldvb : ldkb) + dcol[jj] : 0xFFFFFFF0u;
@@ -483,8 +487,8 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnArgs a) {
   };
   // wait until only this wave's DMAs of the NEWEST tile (3 or 2 per wave) may still be in flight
   auto wait_all_but_newest = [&]() {
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
   };
 
   // per-lane fragment addresses inside ring slot 0 (loop-invariant).  K (A operand, 32x32x16): row 32 u + li, bytes
@@ -847,14 +851,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int6
 static inline bool attn40_legacy() { return tune_env("MIMO_ATTN40_LEGACY", 0) != 0; }
 template <int DT>
 static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)(((a.Nq + 255) / 256) * a.heads * a.B));
+  // 8-wave blocks (512 queries) for long sequences; 4-wave blocks keep the chip full when there are few queries
+  const int nw = tune_env("MIMO_ATTN40_NW", (int64_t)a.Nq * a.heads * a.B >= (int64_t)512 * 1024 ? 8 : 4);
+  const dim3 grid((unsigned)(((a.Nq + 64 * nw - 1) / (64 * nw)) * a.heads * a.B));
 #ifdef MIMO_TUNE
   if (tune_env("MIMO_ATTN40_ABLATE", 0) == 1) {
-    hipLaunchKernelGGL((attn40_kernel<DT, 1>), grid, dim3(256), 0, st, a);
+    if (nw == 8) hipLaunchKernelGGL((attn40_kernel<DT, 8, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((attn40_kernel<DT, 4, 1>), grid, dim3(256), 0, st, a);
     return;
   }
 #endif
-  hipLaunchKernelGGL((attn40_kernel<DT, 0>), grid, dim3(256), 0, st, a);
+  if (nw == 8) hipLaunchKernelGGL((attn40_kernel<DT, 8, 0>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((attn40_kernel<DT, 4, 0>), grid, dim3(256), 0, st, a);
 }
 
 extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,

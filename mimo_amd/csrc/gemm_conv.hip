@@ -162,8 +162,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           // gate tile = the next 16 packed columns; identical lane mapping
           const int ng = (ni + 1 < NR) ? ni + 1 : ni;
           const f32x4 gt = acc[ng][mi] + bv[ng];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
+          if (MIMO_ABLATE(g, F_ABL_NO_GELU)) {
+            v *= gt;
+          } else {
+            const f32x2 g01 = gelu_erf_pk((f32x2){gt[0], gt[1]}), g23 = gelu_erf_pk((f32x2){gt[2], gt[3]});
+            v *= (f32x4){g01.x, g01.y, g23.x, g23.y};
+          }
         }
         if (do_silu) {
 #pragma unroll

@@ -6,6 +6,7 @@ Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, 
 
   small       half-width UNets (4 heads, d = 40/80/160): denoising forward + banks, odd-size forward
   forward512  FULL-SIZE denoising UNet, config-2 shapes: one forward on 2 x 24 latent frames 64x64 (about 4 min, 15 GB)
+  forward768  the same at BASELINE configs[4] shapes: 2 x 24 latent frames 96x96 (768x768; about 10 min, 30 GB)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
   config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
               0, 9, 19; about 70 min and 19 GB on 8 cores)
@@ -92,6 +93,17 @@ def forward512():
     out = forward_case(r3, r2, 64, 24, 320, 9, t=499)
     print(f"full-size forward {time.time()-t0:.0f} s")
     save_file({"fwd_hw64_F24": out}, os.path.join(OUT, "full_unet_forward_512.safetensors"))
+
+
+def forward768():
+    """BASELINE configs[4] shapes: one denoising forward at 768x768 (latent 96x96), 2 x 24 frames, reference bank."""
+    t0 = time.time()
+    r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, 96, 1234, 1235)
+    print(f"full-size reference models built in {time.time()-t0:.0f} s", flush=True)
+    t0 = time.time()
+    out = forward_case(r3, r2, 96, 24, 320, 13, t=499)
+    print(f"768x768 forward {time.time()-t0:.0f} s", flush=True)
+    save_file({"fwd_hw96_F24": out}, os.path.join(OUT, "full_unet_forward_768.safetensors"))
 
 
 def config1():
@@ -241,5 +253,5 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ["small"]
     for w in what:
-        {"small": small, "forward512": forward512, "config1": config1, "config2": config2,
+        {"small": small, "forward512": forward512, "forward768": forward768, "config1": config1, "config2": config2,
          "config2_video": config2_video, "multiwindow": multiwindow}[w]()

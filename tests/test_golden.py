@@ -110,6 +110,23 @@ def test_hip_full_size_forward_vs_reference_golden(full_models):
 
 
 @pytest.mark.gpu
+def test_hip_full_size_forward_768_vs_reference_golden(full_models):
+    """BASELINE configs[4] shapes: ONE denoising forward at 768x768 (latent 96x96: N = 9216 tokens at level 0, d = 40
+    attention over 18432 keys for the cond rows), 2 x 24 frames, against the reference's own code on CPU fp32."""
+    path = os.path.join(GOLD, "full_unet_forward_768.safetensors")
+    if not os.path.exists(path):
+        pytest.skip("768x768 golden fixture not generated")
+    G = gold("full_unet_forward_768.safetensors")
+    ehs, ref_lat, x, pose = case_inputs(96, 24, 320, 13)
+    out = _product_forward(full_models["den"], full_models["ref"], torch.device("cuda:0"), ehs, ref_lat, x, pose, 499)
+    e = rel_l2(out, G["fwd_hw96_F24"])
+    line = f"full-size denoising forward (768x768x24f shapes) fp16 vs reference fp32: rel_l2={e:.2e}"
+    print(line)
+    _report(line)
+    assert e < 1e-3
+
+
+@pytest.mark.gpu
 def test_hip_config1_pipeline_vs_reference_golden(full_models):
     """BASELINE configs[0]: 256x256, 8 frames, 4 DDIM steps, CFG 3.5, full-size models: latents after every step."""
     from mimo_amd.pipeline import Pose2VideoPipeline
@@ -132,7 +149,7 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
     assert video.shape == (1, 3, F, H, W) and bool(torch.isfinite(video).all())
     errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in range(4)]
     print("config-1 latents rel_l2 per step:", ["%.2e" % e for e in errs])
-    assert errs[0] < 1e-3 and errs[-1] < 3e-3  # one forward: 1e-3; four chained forwards accumulate
+    assert errs[0] < 1e-3 and errs[-1] < 1.5e-3  # one forward: 1e-3; measured after four 250-step jumps: 1.13e-3 (x 1.3)
 
 
 @pytest.mark.gpu
@@ -212,4 +229,4 @@ def test_hip_multiwindow_call_vs_reference_golden(full_models):
             f" | decoded frames 0/47: {v0:.2e} {v47:.2e}")
     print(line)
     _report(line)
-    assert e0 < 1e-3 and e3 < 1.5e-3 and max(v0, v47) < 2e-3
+    assert e0 < 1e-3 and e3 < 1e-3 and max(v0, v47) < 1e-3  # measured 1.9e-4 / 9.2e-4 | 6.4e-4 / 6.7e-4: the 1e-3 bar holds on the windowed path

@@ -136,7 +136,9 @@ def test_vae_encode_decode(dev, dtype, H, W):
     out_d = pv.decode(z.to(dev)).sample.cpu()
     e1, e2 = rel_l2(out_m, ref_m), rel_l2(out_d, ref_d)
     report(f"vae {dtype} {H}x{W}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
-    assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
+    # measured fp16: encode 1.5e-3, decode 2.2e-3 (x 1.3); bf16 scales with its 8x coarser mantissa
+    lim = {torch.float16: (2.0e-3, 2.9e-3), torch.bfloat16: (1.6e-2, 2.4e-2)}[dtype]
+    assert e1 < lim[0] and e2 < lim[1]
 
 
 def _run_oracle_unet(o3, o2, x, t, ehs, pose, ref_lat):
@@ -213,7 +215,7 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
     report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W)
-    assert e_lat < {torch.float16: 3e-3, torch.bfloat16: 3e-2}[dtype]
+    assert e_lat < {torch.float16: 1.85e-3, torch.bfloat16: 1.5e-2}[dtype]  # measured 1.41e-3 / 1.1e-2 (x 1.3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -358,4 +360,4 @@ def test_pipeline_call_surface_pil_inputs(dev):
                             torch.stack([to_t(p) for p in poses]), lat, 2, 3.5)
     e = rel_l2(out, vid_o)
     report(f"pipeline __call__ (PIL inputs, HIP CLIP, per-frame backgrounds) fp16: video rel_l2={e:.2e}")
-    assert e < 3e-3
+    assert e < 1.4e-3  # measured 1.06e-3 (x 1.3)

@@ -87,9 +87,9 @@ def med_interleaved(fns, rounds=5, iters=10):
 
 def attn_ab(dt, dev):
     """Spatial attention d = 40: legacy kernel vs attn40_kernel program orders (tune build: MIMO_ATTN40_* knobs)."""
-    variants = [("legacy", {"MIMO_ATTN40_LEGACY": "1"}), ("v2 order0", {"MIMO_ATTN40_ORDER": "0"}),
-                ("v2 order1", {"MIMO_ATTN40_ORDER": "1"}), ("v2 order2", {"MIMO_ATTN40_ORDER": "2"}),
-                ("v2 no-mem", {"MIMO_ATTN40_ABLATE": "1"})]
+    variants = [("legacy", {"MIMO_ATTN40_LEGACY": "1"}), ("v3 4 waves", {"MIMO_ATTN40_NW": "4"}), ("v3 8 waves", {"MIMO_ATTN40_NW": "8"}),
+                ("v3 4w no-mem", {"MIMO_ATTN40_NW": "4", "MIMO_ATTN40_ABLATE": "1"}),
+                ("v3 8w no-mem", {"MIMO_ATTN40_NW": "8", "MIMO_ATTN40_ABLATE": "1"})]
     for (N, C, nb) in [(4096, 320, 48), (1024, 320, 48), (9604, 320, 8)]:
         qkv = torch.randn(nb, N, 3 * C, device=dev).to(dt)
         bank = torch.randn(N, 2 * C, device=dev).to(dt)
@@ -98,7 +98,7 @@ def attn_ab(dt, dev):
 
         def mk(env):
             def f():
-                for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_ORDER", "MIMO_ATTN40_ABLATE"):
+                for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE"):
                     os.environ.pop(kk, None)
                 os.environ.update(env)
                 return ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=nb // 2, q_prescaled=True)
@@ -108,8 +108,8 @@ def attn_ab(dt, dev):
         res = med_interleaved(fns)
         for (name, _), (tmin, tmed), o in zip(variants, res, outs):
             err = float((o - outs[0]).norm() / outs[0].norm())
-            print(f"attn N{N} d40 b{nb} {name:10s}: min {tmin*1e3:7.3f} ms med {tmed*1e3:7.3f} ms  {fl/tmin/1e12:7.1f} TF/s  rel-L2 vs legacy {err:.1e}", flush=True)
-    for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_ORDER", "MIMO_ATTN40_ABLATE"):
+            print(f"attn N{N} d40 b{nb} {name:13s}: min {tmin*1e3:7.3f} ms med {tmed*1e3:7.3f} ms  {fl/tmin/1e12:7.1f} TF/s  rel-L2 vs legacy {err:.1e}", flush=True)
+    for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE"):
         os.environ.pop(kk, None)
 
 
