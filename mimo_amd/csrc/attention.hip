@@ -366,9 +366,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 //     Only then (and on the first tile) S is recomputed and re-referenced: exact softmax arithmetic either way;
 //   * BOTH K and V tiles go global -> LDS by DMA, row-major as they lie in memory (row pitch 80 B), into a 3-deep
 //     ring: the loads of tile t+2 are issued before tile t is consumed and waited for with a COUNTED vmcnt (no VGPR
-//     staging, no compiler-inserted vmcnt(0) drain).  The ablation that removes all loop traffic runs 27 % faster than
-//     the 2-buffer form did: the loop was bound by the latency of loads with one tile of slack, not by bandwidth
-//     (L2 hit rate 95 %).  V^T fragments come out of the row-major V tile with ds_read_b64_tr_b16 (hardware
+//     staging, no compiler-inserted vmcnt(0) drain; +5 % over the 2-buffer form).  Tune-build ablations
+//     (profiles/r2_attn40_ab.txt): never waiting for the DMAs gains 3 %, register staging instead of DMA ties, K/V tiles
+//     contiguous in memory tie, 8-wave blocks lose 12 % — the loop is issue-bound at the power-limited clock, not
+//     memory-bound (L2 hit rate 95 %, fabric fetch 0.7 GB); the variant that re-reads ONE tile runs 27 % faster only
+//     because constant operands let the chip clock higher.  V^T fragments come out of the row-major V tile with ds_read_b64_tr_b16 (hardware
 //     transpose: lane (g, i) receives V[kv0 + j][d0 + i], j < 4); K column 40 (the bias column of the reference-max
 //     trick) and V^T rows 40..47 (ones-row + padding) are constant LDS slots the fragment addresses point at;
 //   * 1-D grid, XCD-aware: consecutive logical blocks (same batch row and head = same K/V) run on one XCD and hit in
@@ -377,10 +379,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tiles' K / V):
-// the compute-only time of the loop, for telling a memory-latency bound from an issue bound
+// the compute-only time of the loop; 2 = DMAs issued but never waited for (stale tiles): issue cost without wait cost
 // NW = waves per block (4 | 8): a block covers 64 NW queries.  The per-tile DMA work (10 instructions, ~100+ issue cycles
 // each inside a busy phase) is fixed per block, so 8 waves halve its cost per FLOP.
-template <int DT, int NW, int ABL = 0>
+// STAGE: 0 = tiles by LDS-DMA (asm, counted vmcnt); 1 = tiles through registers: plain buffer loads issued at the top of the
+// iteration two tiles ahead, ds_write_b128 into the ring at its end (loads the compiler counts itself; NW = 4 only)
+template <int DT, int NW, int ABL = 0, int STAGE = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
   constexpr int NB = 3;                     // ring depth (tiles t, t+1, t+2)
@@ -446,8 +450,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   const uint16_t* kb0 = a.k + (int64_t)b * a.Nk * a.ldk;
   const uint16_t* vb0 = a.v + (int64_t)b * a.Nk * a.ldv;
 
-  // ---- tile DMA: K and V are 320 16-byte chunks each = 5 + 5 wave-DMAs per tile; wave w issues DMAs w, w + NW, ... < 10 of
-  // the list [K0..K4, V0..V4]: 3 | 3 | 2 | 2 per wave (NW = 4), 2 | 2 | 1 x 6 (NW = 8): the counts the vmcnt waits rely on ----
+  // ---- tile DMA: K and V are 320 16-byte chunks each = 5 + 5 wave-DMAs per tile.  Wave w issues K piece w, V piece w and
+  // (w = 0) K piece 4 / (w = 1) V piece 4: 3 | 3 | 2 | 2 DMAs per wave (NW = 4; with NW = 8 waves 4..7 take the V pieces and
+  // waves 0 / 4 the fifth pieces: 2 | 1 | 1 | 1 | 2 | 1 | 1 | 1) — the counts the vmcnt waits below rely on.
+  // The no-wait ablation showed the loop pays for ISSUING these DMAs (instructions), not for waiting on them: everything
+  // lane-dependent is loop-invariant (voff*), the tile's first row travels in the scalar offset, descriptors are picked by
+  // scalar selects, and only a ragged last tile computes row masks. ----
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t p64 = reinterpret_cast<uint64_t>(ptr);
     i32x4 r;
@@ -455,40 +463,86 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     return r;
   };
   const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0];
-  constexpr int NJ = (10 + NW - 1) / NW;  // DMAs of the busiest wave
-  int drow[NJ];       // tile row of this lane's chunk in DMA jj
-  unsigned dcol[NJ];  // byte offset of the chunk inside a token row
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + NW * jj;                // DMA index 0..9 (the last jj exists for waves 0, 1 only)
-    const int c = 64 * (j >= 5 ? j - 5 : j) + lane;
-    drow[jj] = c / 5;
-    dcol[jj] = (unsigned)((head * D + (c - drow[jj] * 5) * 8) * 2);
+  // piece p (0..4) of a tile = chunks 64 p .. 64 p + 63; this lane's chunk: row c / 5, 16-byte column c % 5
+  constexpr int NJ = NW == 4 ? 3 : 2;       // DMAs of the busiest wave
+  const int pA = NW == 4 ? wave : (wave & 3);               // piece of this wave's first DMA ...
+  const bool vA = NW == 4 ? false : wave >= 4;              // ... which is a K piece (NW = 4) or K / V by wave half (NW = 8)
+  const bool has3 = NW == 4 ? wave < 2 : (wave & 3) == 0;   // this wave also moves a fifth piece
+  const bool v3 = NW == 4 ? wave == 1 : wave == 4;          // ... of V (else of K)
+  const unsigned ldk1 = (unsigned)(a.ldk * 2), ldv1 = (unsigned)(a.ldv * 2), ldk2 = (unsigned)(a.ldk2 * 2), ldv2 = (unsigned)(a.ldv2 * 2);
+  int prow[2];
+  unsigned pcol[2];
+  {
+    const int c0 = 64 * pA + lane, c1 = 256 + lane;
+    prow[0] = c0 / 5; pcol[0] = (unsigned)((head * D + (c0 - prow[0] * 5) * 8) * 2);
+    prow[1] = c1 / 5; pcol[1] = (unsigned)((head * D + (c1 - prow[1] * 5) * 8) * 2);
   }
+  // byte offsets of this lane's chunks relative to the tile's first row, per segment (self | bank)
+  const unsigned voffK[2] = {(unsigned)prow[0] * ldk1 + pcol[0], (unsigned)prow[0] * ldk2 + pcol[0]};
+  const unsigned voffV[2] = {(unsigned)prow[0] * ldv1 + pcol[0], (unsigned)prow[0] * ldv2 + pcol[0]};
+  const unsigned voff3[2] = {(unsigned)prow[1] * (v3 ? ldv1 : ldk1) + pcol[1], (unsigned)prow[1] * (v3 ? ldv2 : ldk2) + pcol[1]};
+  const i32x4 rk1 = make_rsrc(kb0, (unsigned)((int64_t)a.Nk * ldk1)), rv1 = make_rsrc(vb0, (unsigned)((int64_t)a.Nk * ldv1));
+  const i32x4 rk2 = make_rsrc(has2 ? a.k2 : kb0, has2 ? (unsigned)((int64_t)a.Nk2 * ldk2) : 0u);
+  const i32x4 rv2 = make_rsrc(has2 ? a.v2 : vb0, has2 ? (unsigned)((int64_t)a.Nk2 * ldv2) : 0u);
+  constexpr unsigned OOBA = 0x80000000u;  // stays out of range whether or not the (< 2 GiB) scalar offset takes part in the check
+  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(r), "s"(soff), "s"(dst) : "memory");
+  };
   auto issue_tile = [&](int t, int buf) {
+    const bool s2 = t >= T0;  // wave-uniform
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const i32x4 rk = s2 ? rk2 : rk1, rv = s2 ? rv2 : rv1;
+    const unsigned soffk = (unsigned)kv0 * (s2 ? ldk2 : ldk1), soffv = (unsigned)kv0 * (s2 ? ldv2 : ldv1);
+    unsigned oK = s2 ? voffK[1] : voffK[0], oV = s2 ? voffV[1] : voffV[0], o3 = s2 ? voff3[1] : voff3[0];
+    if (kv0 + KV_TILE > nk) {  // ragged last tile of a segment: rows past the end read zeros
+      if (kv0 + prow[0] >= nk) oK = oV = OOBA;
+      if (kv0 + prow[1] >= nk) o3 = OOBA;
+    }
+    const unsigned dK = smem_base + (unsigned)(K_OFF + buf * TILEB), dV = smem_base + (unsigned)(V_OFF + buf * TILEB);
+    if (NW == 4) {
+      dma(rk, oK, soffk, dK + 1024u * (unsigned)pA);
+      dma(rv, oV, soffv, dV + 1024u * (unsigned)pA);
+    } else {
+      dma(vA ? rv : rk, vA ? oV : oK, vA ? soffv : soffk, (vA ? dV : dK) + 1024u * (unsigned)pA);
+    }
+    if (has3) dma(v3 ? rv : rk, o3, v3 ? soffv : soffk, (v3 ? dV : dK) + 4096u);
+  };
+  // wait until only this wave's DMAs of the NEWEST tile may still be in flight
+  auto wait_all_but_newest = [&]() {
+    if (has3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
+  };
+
+  // ---- register staging (STAGE = 1): thread `tid` moves K chunk tid and V chunk tid; threads < 64 also K chunk 256 + tid,
+  // threads 64..127 V chunk 192 + tid.  The LDS image is the same lane-linear row-major tile the DMA writes. ----
+  u32x4 sreg[3];
+  const int srow0 = tid / 5, srow2 = (256 + (tid & 63)) / 5;
+  const unsigned scol0 = (unsigned)((head * D + (tid - srow0 * 5) * 8) * 2), scol2 = (unsigned)((head * D + ((256 + (tid & 63)) - srow2 * 5) * 8) * 2);
+  const bool s3 = tid < 128, s3v = tid >= 64;  // has a third chunk / it is a V chunk
+  auto stage_loads = [&](int t) {
     const bool s2 = t >= T0;
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
-    const unsigned ldkb = (unsigned)((s2 ? a.ldk2 : a.ldk) * 2), ldvb = (unsigned)((s2 ? a.ldv2 : a.ldv) * 2);
-    const i32x4 rk = make_rsrc(s2 ? a.k2 : kb0, (unsigned)((int64_t)nk * ldkb));
-    const i32x4 rv = make_rsrc(s2 ? a.v2 : vb0, (unsigned)((int64_t)nk * ldvb));
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int j = wave + NW * jj;
-      if (j >= 10) break;  // wave-uniform
-      const bool isv = j >= 5;          // wave-uniform
-      const bool ok = kv0 + drow[jj] < nk;
-      const unsigned off = ok ? (unsigned)(kv0 + drow[jj]) * (isv ? ldvb : ldkb) + dcol[jj] : 0xFFFFFFF0u;
-      const unsigned dst = smem_base + (unsigned)((isv ? V_OFF : K_OFF) + buf * TILEB + 1024 * (isv ? j - 5 : j));
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off), "s"(isv ? rv : rk), "s"(dst) : "memory");
+    const unsigned ldkb = s2 ? ldk2 : ldk1, ldvb = s2 ? ldv2 : ldv1;
+    const __amdgpu_buffer_rsrc_t bk = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? a.k2 : kb0), 0, (int)((int64_t)nk * ldkb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bv = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? a.v2 : vb0), 0, (int)((int64_t)nk * ldvb), 0x00020000);
+    const bool ok0 = kv0 + srow0 < nk, ok2 = kv0 + srow2 < nk;
+    sreg[0] = __builtin_amdgcn_raw_buffer_load_b128(bk, ok0 ? (unsigned)srow0 * ldkb + scol0 : OOBA, (unsigned)kv0 * ldkb, 0);
+    sreg[1] = __builtin_amdgcn_raw_buffer_load_b128(bv, ok0 ? (unsigned)srow0 * ldvb + scol0 : OOBA, (unsigned)kv0 * ldvb, 0);
+    if (s3) {
+      if (s3v) sreg[2] = __builtin_amdgcn_raw_buffer_load_b128(bv, ok2 ? (unsigned)srow2 * ldvb + scol2 : OOBA, (unsigned)kv0 * ldvb, 0);
+      else sreg[2] = __builtin_amdgcn_raw_buffer_load_b128(bk, ok2 ? (unsigned)srow2 * ldkb + scol2 : OOBA, (unsigned)kv0 * ldkb, 0);
     }
   };
-  // wait until only this wave's DMAs of the NEWEST tile (3 or 2 per wave) may still be in flight
-  auto wait_all_but_newest = [&]() {
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
+  auto stage_write = [&](int buf) {
+    unsigned char* kd = smem + K_OFF + buf * TILEB;
+    unsigned char* vd = smem + V_OFF + buf * TILEB;
+    *reinterpret_cast<u32x4*>(kd + 16 * tid) = sreg[0];
+    *reinterpret_cast<u32x4*>(vd + 16 * tid) = sreg[1];
+    if (s3) *reinterpret_cast<u32x4*>((s3v ? vd : kd) + 16 * (256 + (tid & 63))) = sreg[2];
   };
 
   // per-lane fragment addresses inside ring slot 0 (loop-invariant).  K (A operand, 32x32x16): row 32 u + li, bytes
@@ -595,7 +649,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   auto tile = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
     constexpr int RD = ABL == 1 ? 0 : CUR;   // (ablation: every tile reads slot 0)
-    if (t + 2 < T && ABL != 1) issue_tile(t + 2, (CUR + 2) % NB);  // that slot was last read in iteration t-1 (barrier passed)
+    if (t + 2 < T && ABL != 1) {  // slot (CUR + 2) % NB was last read in iteration t-1 (barrier passed)
+      if (STAGE == 1) stage_loads(t + 2);
+      else issue_tile(t + 2, (CUR + 2) % NB);
+    }
     const bool s2 = t >= T0;
     const int nk = s2 ? a.Nk2 : a.Nk;
     const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
@@ -661,19 +718,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
         }
       }
     if (t + 1 < T) {
-      // tile t+1 (issued one iteration ago) has to be in LDS; tile t+2 (issued above) may stay in flight
-      if (t + 2 < T && ABL != 1) wait_all_but_newest();
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // publishes tile t+1; every wave is done reading slot CUR
+      if (STAGE == 1) {
+        if (t + 2 < T && ABL != 1) stage_write((CUR + 2) % NB);  // tile t+2: loaded at the top, readable after two barriers
+      } else {
+        // tile t+1 (issued one iteration ago) has to be in LDS; tile t+2 (issued above) may stay in flight
+        if (ABL == 2) {  // (ablation: DMAs issued, never waited for — the tiles read may be stale)
+        } else if (t + 2 < T && ABL != 1) wait_all_but_newest();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();  // publishes the staged tiles; every wave is done reading slot CUR
     }
   };
 
   // ---- pipeline: two tiles in flight ahead of the one being consumed; ONE barrier per tile ----
-  issue_tile(0, 0);
-  if (T > 1) issue_tile(1, 1);
-  if (T > 1) wait_all_but_newest();
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // tile 0 and the constant slots are visible
+  if (STAGE == 1) {
+    stage_loads(0);
+    stage_write(0);
+    if (T > 1) {
+      stage_loads(1);
+      stage_write(1);
+    }
+  } else {
+    issue_tile(0, 0);
+    if (T > 1) issue_tile(1, 1);
+    if (T > 1) wait_all_but_newest();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();  // tiles 0 (and 1) and the constant slots are visible
 
   for (int t = 0; t < T; t += 3) {
     tile(IC2<0>{}, t);
@@ -851,8 +922,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, int6
 static inline bool attn40_legacy() { return tune_env("MIMO_ATTN40_LEGACY", 0) != 0; }
 template <int DT>
 static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
-  // 8-wave blocks (512 queries) for long sequences; 4-wave blocks keep the chip full when there are few queries
-  const int nw = tune_env("MIMO_ATTN40_NW", (int64_t)a.Nq * a.heads * a.B >= (int64_t)512 * 1024 ? 8 : 4);
+  // 4-wave blocks (256 queries) by default: 8-wave blocks halve the DMA work per FLOP but measured 12 % slower
+  // (one block per CU: nothing overlaps its per-tile barrier; profiles/r2_attn40_ab.txt)
+  const int nw = tune_env("MIMO_ATTN40_NW", 4);
   const dim3 grid((unsigned)(((a.Nq + 64 * nw - 1) / (64 * nw)) * a.heads * a.B));
 #ifdef MIMO_TUNE
   if (tune_env("MIMO_ATTN40_ABLATE", 0) == 1) {
@@ -860,9 +932,20 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((attn40_kernel<DT, 4, 1>), grid, dim3(256), 0, st, a);
     return;
   }
+  if (tune_env("MIMO_ATTN40_ABLATE", 0) == 2) {
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 2>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (tune_env("MIMO_ATTN40_STAGE", 0) == 1 && nw == 4) {
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 1>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (nw == 8) {
+    hipLaunchKernelGGL((attn40_kernel<DT, 8, 0>), grid, dim3(512), 0, st, a);
+    return;
+  }
 #endif
-  if (nw == 8) hipLaunchKernelGGL((attn40_kernel<DT, 8, 0>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((attn40_kernel<DT, 4, 0>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((attn40_kernel<DT, 4, 0>), grid, dim3(256), 0, st, a);
 }
 
 extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,

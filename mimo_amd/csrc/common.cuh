@@ -106,28 +106,6 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
 }
 
-// the same function on a pair: the polynomial / scaling steps are packed-f32 instructions (v_pk_fma_f32, v_pk_mul_f32:
-// one issue slot for two values), only rcp / exp2 / the sign transfer stay per element.  Identical operations and
-// roundings as gelu_erf_f.  The GEGLU epilogue is a pure-VALU phase executed by every wave of the block at once (nothing
-// for the MFMA pipe to do meanwhile), so its instruction count is time.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
-  const f32x2 z = x * 0.70710678118654752440f;
-  const f32x2 ax = {fabsf(z.x), fabsf(z.y)};
-  const f32x2 d = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
-  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  f32x2 p = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
-  p = __builtin_elementwise_fma(p, t, (f32x2){1.421413741f, 1.421413741f});
-  p = __builtin_elementwise_fma(p, t, (f32x2){-0.284496736f, -0.284496736f});
-  p = __builtin_elementwise_fma(p, t, (f32x2){0.254829592f, 0.254829592f});
-  p = p * t;
-  const f32x2 a2 = -ax * ax * 1.4426950408889634f;
-  const f32x2 e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-  f32x2 r = __builtin_elementwise_fma(-p, e, (f32x2){1.0f, 1.0f});
-  r = (f32x2){copysignf(r.x, z.x), copysignf(r.y, z.y)};
-  return 0.5f * x * (1.0f + r);
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -47,7 +47,7 @@ struct GemmArgs {
   const float* img_bias;
   const void* res;
   int64_t lda, ldw, ldo, ldr, M, rows_per_img, ldib;
-  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor extents (each operand < 4 GiB)
+  unsigned a_bytes, a2_bytes, w_bytes;  // buffer-descriptor extents (each operand < 2 GiB)
   int N, K;
   float out_scale;
   unsigned flags;
@@ -68,7 +68,25 @@ struct GemmArgs {
   float ln_eps;
   int64_t ln_rows_per_frame;
   int ln_pe_frames;
+  unsigned long long* dbg;  // MIMO_TUNE builds: cycle-counter trace of block 0 (null otherwise)
 };
+
+// Trace points (tune build, MIMO_GEMM_TRACE=1): thread 0 of block 0 appends (tag << 56 | s_memtime) to g.dbg.
+#ifdef MIMO_TUNE
+#define MIMO_TRACE(g, idx, tag)                                                                                    \
+  do {                                                                                                             \
+    if ((g).dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (idx) < 4000u)                        \
+      (g).dbg[(idx)++] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+  } while (0)
+#define MIMO_TRACE_REAL(g, idx, tag)                                                                                  \
+  do {                                                                                                                \
+    if ((g).dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (idx) < 4000u)                           \
+      (g).dbg[(idx)++] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull); \
+  } while (0)
+#else
+#define MIMO_TRACE(g, idx, tag) do { (void)(idx); } while (0)
+#define MIMO_TRACE_REAL(g, idx, tag) do { (void)(idx); } while (0)
+#endif
 
 template <int V>
 struct IC {
@@ -162,12 +180,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           // gate tile = the next 16 packed columns; identical lane mapping
           const int ng = (ni + 1 < NR) ? ni + 1 : ni;
           const f32x4 gt = acc[ng][mi] + bv[ng];
-          if (MIMO_ABLATE(g, F_ABL_NO_GELU)) {
-            v *= gt;
-          } else {
-            const f32x2 g01 = gelu_erf_pk((f32x2){gt[0], gt[1]}), g23 = gelu_erf_pk((f32x2){gt[2], gt[3]});
-            v *= (f32x4){g01.x, g01.y, g23.x, g23.y};
-          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
         }
         if (do_silu) {
 #pragma unroll
@@ -570,8 +584,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   const int kt_lo = (int)(((int64_t)g.nkt * blockIdx.y) / gridDim.y);
   const int kt_hi = (int)(((int64_t)g.nkt * (blockIdx.y + 1)) / gridDim.y);
 
-  // issue the LOADS DMAs of K-tile kt into ring slot `slot` (kt >= kt_hi: all-zero DMAs keep the counts uniform)
-  auto load_tile = [&](int kt, int slot) {
+  // MODE 2 loader (the nearest-neighbour gather needs a per-tap source coordinate): issue the LOADS DMAs of K-tile kt
+  // into ring slot `slot` (kt >= kt_hi: all-zero DMAs keep the counts uniform)
+  auto load_tile_general = [&](int kt, int slot) {
     // offsets are computed on (uniform) branches; the DMAs themselves are issued once, after the join
     unsigned offA[NAJ], kw = 0;
     bool cok = false;
@@ -629,6 +644,126 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
       dma(rW, (cok & (b_base[j] != OOB)) ? b_base[j] + kw : OOB, slot_base + 16u * ((BM + b_row0[j]) * 8));
   };
 
+
+  // ---- MODE 0 / 1 loader: everything a lane contributes to an address is loop-invariant ----
+  // The K-loop of the 256x320 tile has 80 MFMAs per wave per K-tile; a loader that re-derives (tap, chunk) with integer
+  // divisions, re-checks the image border per row and rebuilds descriptors per tile spends several hundred scalar/vector
+  // instructions per K-tile and the kernel becomes issue-bound.  Here a lane keeps, per A pass, the byte offset of tap
+  // (0,0) of its row and a 9-bit mask of the taps that fall inside the image; the K-tile contributes a scalar tap offset
+  // (one v_add) and two scalar `soffset`s (channel chunk, weight column); the B offsets never change.  Invalid lanes use
+  // OOBA: every descriptor is < 2 GiB (checked on the host), so OOBA + soffset is out of range whether or not the
+  // hardware adds soffset before the range check.
+  constexpr unsigned OOBA = 0x80000000u;
+  unsigned fa_mask[NAJ], fb_base[NBJ];
+  if constexpr (MODE != 2) {
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) {
+      unsigned mk = 0;
+      if (CONV) {
+        for (int ky = 0; ky < g.ks; ++ky)
+          for (int kx = 0; kx < g.ks; ++kx)
+            if (a_ok[j] && (unsigned)(a_iy0[j] + ky) < (unsigned)g.Hin && (unsigned)(a_ix0[j] + kx) < (unsigned)g.Win)
+              mk |= 1u << (ky * g.ks + kx);
+        if (!a_ok[j]) a2_base[j] = OOBA;
+      } else if (!a_ok[j]) {
+        a_base[j] = OOBA;
+      }
+      fa_mask[j] = mk;
+    }
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) fb_base[j] = b_base[j] == OOB ? OOBA : b_base[j];
+  }
+  const i32x4 rA1 = make_rsrc(g.A, g.a_bytes);
+  const i32x4 rA2 = make_rsrc(g.A2, g.a2_bytes);
+  // lanes whose 16-byte chunk exists in the LAST (ragged) channel chunk of a segment
+  const bool tail1_ok = CONV ? (g.chunks1 - 1) * BK + sc * 8 < g.Cin : (g.nkt - 1) * BK + sc * 8 < g.K;
+  const bool tail2_ok = CONV ? (g.chunks2 - 1) * BK + sc * 8 < g.Cin2 : true;
+  const bool ragged1 = CONV ? (g.Cin & (BK - 1)) != 0 : (g.K & (BK - 1)) != 0;
+  const bool ragged2 = CONV && (g.Cin2 & (BK - 1)) != 0;
+  // scalar cursor: the K-tile the next load_next() fetches
+  int ld_kt = kt_lo, ld_tap = 0, ld_chunk = 0;  // conv: ld_tap == ntaps marks the shortcut segment
+  const int ntaps = CONV ? g.ks * g.ks : 1;
+  const bool tap_inner = g.flags & F_TAP_INNER;
+  if (CONV && MODE != 2) {
+    const int ntt = ntaps * g.chunks1;
+    if (kt_lo >= ntt) { ld_tap = ntaps; ld_chunk = kt_lo - ntt; }
+    else if (tap_inner) { ld_chunk = kt_lo / ntaps; ld_tap = kt_lo - ld_chunk * ntaps; }
+    else { ld_tap = kt_lo / g.chunks1; ld_chunk = kt_lo - ld_tap * g.chunks1; }
+  }
+  auto dma_s = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(lds_base) : "memory", "m0");
+  };
+  auto load_next = [&](int slot) {
+    unsigned offA[NAJ], offB[NBJ], soffA, soffW;
+    bool seg2 = false, ragged_now;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) offB[j] = fb_base[j];
+    if (CONV) {
+      seg2 = ld_tap >= ntaps;
+      if (!seg2) {
+        const unsigned ky = (unsigned)(ld_tap * 11) >> 5, kx = (unsigned)ld_tap - ky * (unsigned)g.ks;  // ks in {1, 3}
+        const unsigned tap_off = (ky * (unsigned)g.Win + kx) * (unsigned)g.Cin * 2u;
+        const unsigned bit = 1u << ld_tap;
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) offA[j] = (fa_mask[j] & bit) ? a_base[j] + tap_off : OOBA;
+        soffA = (unsigned)ld_chunk * (BK * 2u);
+        soffW = (unsigned)(ld_tap * g.Cin) * 2u + soffA;
+        ragged_now = ragged1 && ld_chunk == g.chunks1 - 1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) offA[j] = a2_base[j];
+        soffA = (unsigned)ld_chunk * (BK * 2u);
+        soffW = (unsigned)(ntaps * g.Cin) * 2u + soffA;
+        ragged_now = ragged2 && ld_chunk == g.chunks2 - 1;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) offA[j] = a_base[j];
+      soffA = soffW = (unsigned)ld_kt * (BK * 2u);
+      ragged_now = ragged1 && ld_kt == g.nkt - 1;
+    }
+    if (ragged_now) {  // (uniform, rare) the last chunk of a ragged channel count: some lanes have no data
+      const bool ok = seg2 ? tail2_ok : tail1_ok;
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) offA[j] = ok ? offA[j] : OOBA;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) offB[j] = ok ? offB[j] : OOBA;
+    }
+    if (ld_kt >= kt_hi) {  // (uniform) past the end: all-zero DMAs keep the per-wave counts uniform
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) offA[j] = OOBA;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) offB[j] = OOBA;
+    }
+    const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
+    const i32x4 rsel = seg2 ? rA2 : rA1;
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) dma_s(rsel, offA[j], soffA, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) dma_s(rW, offB[j], soffW, slot_base + 16u * ((BM + b_row0[j]) * 8));
+    // advance the cursor
+    ++ld_kt;
+    if (CONV) {
+      if (seg2) {
+        ++ld_chunk;
+      } else if (tap_inner) {
+        if (++ld_tap == ntaps) {
+          ld_tap = 0;
+          if (++ld_chunk == g.chunks1) { ld_tap = ntaps; ld_chunk = 0; }
+        }
+      } else if (++ld_chunk == g.chunks1) {
+        ld_chunk = 0;
+        ++ld_tap;
+      }
+    }
+  };
+  // K-tiles are requested in order (kt_lo, kt_lo + 1, ...): the fast loader ignores `kt` and follows its own cursor
+  auto load_tile = [&](int kt, int slot) {
+    if constexpr (MODE == 2) load_tile_general(kt, slot);
+    else load_next(slot);
+  };
+
   f32x4 acc[NR][MT];
 #pragma unroll
   for (int ni = 0; ni < NR; ++ni)
@@ -655,22 +790,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   };
   // Waves that share a SIMD (w, w+4, ...) issue their DMAs at different points of the K-tile, so that a
   // SIMD's matrix pipe is not left idle while all of its waves sit in the (slow-to-issue) DMA instructions.
-  const bool late = (g.flags & F_STAGGER) && ((wave >> 2) & 1);
+  const bool late = (g.flags & F_STAGGER) && ((wave_u >> 2) & 1);  // wave_u: the branch must be uniform for the compiler too
 
   // One K-tile: wait until everything but the newest NSTAGE-2 tiles of THIS wave has landed, barrier (all
   // waves' parts landed AND every wave is done reading the slot about to be recycled), refill that slot with
   // tile kt + NSTAGE - 1, then run the MFMAs of tile kt while the DMAs fly.
+  unsigned tr = 0;
   auto step = [&](auto slot_c, int kt) {
     constexpr int S = decltype(slot_c)::value;
+    MIMO_TRACE(g, tr, 2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+    MIMO_TRACE(g, tr, 7);
     __syncthreads();
+    MIMO_TRACE(g, tr, 3);
     const bool dma_on = !MIMO_ABLATE(g, F_ABL_NO_DMA), mfma_on = !MIMO_ABLATE(g, F_ABL_NO_MFMA);
     if (dma_on && !late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
     if (mfma_on) compute(slot_c, 0);
     if (dma_on && late) load_tile(kt + NSTAGE - 1, (S + NSTAGE - 1) % NSTAGE);
     if (mfma_on) compute(slot_c, 1);
+    MIMO_TRACE(g, tr, 4);
   };
 
+  MIMO_TRACE_REAL(g, tr, 0xfe);
+  MIMO_TRACE(g, tr, 1);
 #pragma unroll
   for (int i = 0; i < NSTAGE - 1; ++i) load_tile(kt_lo + i, i);
   for (int kt = kt_lo; kt < kt_hi; kt += NSTAGE) {
@@ -679,18 +821,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
     if (NSTAGE > 2 && kt + 2 < kt_hi) step(IC<2 % NSTAGE>{}, kt + 2);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
+  MIMO_TRACE(g, tr, 5);
 
   if constexpr (EPI == 1) {
     tile_epilogue_ln<DT, NR, MT, BM, WN>(g, acc, M0, wm, wn, lg, li, reinterpret_cast<float*>(&smem[NSTAGE * STAGE]));
   } else {
+    bool done = false;
     if constexpr (WM * WN <= 8) {  // (the 16-wave tiles have a 128-register budget: no room for a second epilogue)
       if (g.colstats) {
         tile_epilogue_stats<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li);
-        return;
+        done = true;
       }
     }
-    tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
+    if (!done) tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
   }
+#ifdef MIMO_TUNE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MIMO_TRACE(g, tr, 6);
+  MIMO_TRACE_REAL(g, tr, 0xff);
 }
 
 // Persistent dense GEMM (MODE 0, 2-deep ring): the grid is ONE resident set of blocks; block b walks tiles b, b + grid, ...
@@ -757,18 +906,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
   unsigned ld_v = blockIdx.x;
   int ld_kt = 0;
   set_tile(ld_v);
+  // lane offsets inside the tile never change (the K-tile goes into the scalar soffset; rows beyond the tile are clipped
+  // by the descriptors, whose extents are < 2 GiB so that OOBA + soffset stays out of range)
+  constexpr unsigned OOBA = 0x80000000u;
+  unsigned pa_off[NAJ], pb_off[NBJ];
+#pragma unroll
+  for (int j = 0; j < NAJ; ++j) pa_off[j] = a_thr + j * a_pass;
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) pb_off[j] = (j < NBJ - 1 || b_tail_ok) ? b_thr + j * b_pass : OOBA;
+  const bool ragged = (g.K & (BK - 1)) != 0;
+  const bool tail_ok = (nkt - 1) * BK + sc * 8 < g.K;
+  auto dma_s = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(lds_base) : "memory", "m0");
+  };
   auto issue = [&](int slot) {
     const unsigned kw = (unsigned)(ld_kt * BK * 2);
-    const bool cok = ld_kt * BK + sc * 8 < g.K;  // only the last K-tile of a ragged K can fail
+    unsigned offA[NAJ], offB[NBJ];
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) offA[j] = pa_off[j];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) offB[j] = pb_off[j];
+    if (ragged && ld_kt == nkt - 1) {  // (uniform) only the last K-tile of a ragged K has lanes without data
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) offA[j] = tail_ok ? offA[j] : OOBA;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) offB[j] = tail_ok ? offB[j] : OOBA;
+    }
     const unsigned slot_base = smem_base + 16u * (unsigned)(slot * STAGE);
 #pragma unroll
-    for (int j = 0; j < NAJ; ++j)
-      dma(rA, cok ? a_thr + j * a_pass + kw : OOB, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
+    for (int j = 0; j < NAJ; ++j) dma_s(rA, offA[j], kw, slot_base + 16u * ((wave_u * 8 + PASS * j) * 8));
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
-      const bool ok = cok && (j < NBJ - 1 || b_tail_ok);
       const unsigned r0 = 8 * wave_u + PASS * j;
-      dma(rW, ok ? b_thr + j * b_pass + kw : OOB, slot_base + 16u * ((BM + (r0 < (unsigned)BN ? r0 : (unsigned)BN)) * 8));
+      dma_s(rW, offB[j], kw, slot_base + 16u * ((BM + (r0 < (unsigned)BN ? r0 : (unsigned)BN)) * 8));
     }
     if (++ld_kt == nkt) {
       ld_kt = 0;
@@ -778,6 +949,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
   };
   const bool late = (g.flags & F_STAGGER) && ((wave_u >> 2) & 1);
 
+  unsigned tr = 0;
+  MIMO_TRACE_REAL(g, tr, 0xfe);
+  MIMO_TRACE(g, tr, 1);
   issue(0);
   int slot = 0;
   for (unsigned cv = blockIdx.x; cv < ntiles; cv += gridDim.x) {
@@ -790,8 +964,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
       // vmcnt(0): with a 2-deep ring every wait is a full drain anyway; it also retires the previous epilogue's stores
       // (waiting at the END of the K-tile instead, so that the stores retire under the next tile's first MFMAs,
       // measured 3-8 % slower)
+      MIMO_TRACE(g, tr, 2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MIMO_TRACE(g, tr, 7);
       __syncthreads();
+      MIMO_TRACE(g, tr, 3);
       const uint4* sa = &smem[slot * STAGE];
       const uint4* sb = sa + BM * 8;
       if (!late) issue(slot ^ 1);
@@ -810,7 +987,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
           for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
       }
       slot ^= 1;
+      MIMO_TRACE(g, tr, 4);
     }
+    MIMO_TRACE(g, tr, 5);
     const unsigned Lc = xcd_remap(cv, ntiles);
     const int64_t M0 = (int64_t)(Lc / (unsigned)g.tiles_n) * BM;
     const int N0 = (int)(Lc % (unsigned)g.tiles_n) * BN;
@@ -821,8 +1000,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
     } else {
       tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
     }
+    MIMO_TRACE(g, tr, 6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
+  MIMO_TRACE_REAL(g, tr, 0xff);
 }
 
 // Split-K reduction + the full epilogue: out = epi(sum_s partial[s]); one thread per 4 consecutive columns.
@@ -901,8 +1082,31 @@ inline int cus_() {
   return cus;
 }
 
+#ifdef MIMO_TUNE
+inline unsigned long long* trace_buf() {
+  static unsigned long long* buf = [] {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096 * sizeof(unsigned long long)) != hipSuccess) return (unsigned long long*)nullptr;
+    (void)hipMemset(p, 0, 4096 * sizeof(unsigned long long));
+    return (unsigned long long*)p;
+  }();
+  return buf;
+}
+// copies the trace of the most recent traced launch to `dst` (n entries <= 4096) and clears the device buffer
+extern "C" int mimo_tune_trace(unsigned long long* dst, int n) {
+  if (!trace_buf() || n > 4096) return MIMO_EINVAL;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(dst, trace_buf(), (size_t)n * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemset(trace_buf(), 0, 4096 * 8);
+  return (int)e;
+}
+#endif
+
 template <int DT, int MODE, int NR>
 int launch_nr(GemmArgs& g, hipStream_t st) {
+#ifdef MIMO_TUNE
+  g.dbg = tune_env("MIMO_GEMM_TRACE", 0) ? trace_buf() : nullptr;
+#endif
   // Tile configurations (WM x WN waves, ring depth):
   //   S  2x2, 2 stages: 128 x 32NR tile, 2 blocks/CU          — small / skinny problems
   //   L  4x2, 3 stages: 256 x 32NR tile, 1 block/CU
@@ -1077,7 +1281,7 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
   if (int rc = check_ext(ext, g, M, N, flags)) return rc;
   if (g.ln_out && ((flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || ldo != N || (residual && ldr != N))) return MIMO_EINVAL;
   const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
-  if (ab >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;  // operands are addressed with 32-bit offsets
+  if (ab >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // 32-bit offsets; 2 GiB keeps OOBA + soffset out of range
   g.a_bytes = (unsigned)ab; g.a2_bytes = 0; g.w_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIMO_F16) return launch<MIMO_F16, 0>(g, st);
@@ -1127,7 +1331,7 @@ extern "C" int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const
   if (int rc = check_ext(ext, g, g.M, g.N, flags)) return rc;
   {
     const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
-    if (ab >= 0xFFFFFFF0LL || a2b >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0LL) return MIMO_EINVAL;
+    if (ab >= 0x80000000LL || a2b >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // see OOBA
     g.a_bytes = (unsigned)ab; g.a2_bytes = (unsigned)a2b; g.w_bytes = (unsigned)wb;
   }
   const bool ups = p->Hup > 0;

@@ -238,11 +238,13 @@ class Pose2VideoPipeline:
         -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
         dt = self.vae.compute_dtype
         outs = []
-        for i in range(0, images.shape[0], self.vae_batch):
-            if images.shape[-1] == 8 and images.dtype == dt:
-                tok = images[i:i + self.vae_batch].contiguous()
+        tokens_in = images.shape[-1] == 8 and images.dtype == dt
+        nb = min(self.vae_batch, self.vae.max_images(*(images.shape[1:3] if tokens_in else images.shape[-2:])))
+        for i in range(0, images.shape[0], nb):
+            if tokens_in:
+                tok = images[i:i + nb].contiguous()
             else:
-                tok = ops.ncfhw_to_tokens(images[i:i + self.vae_batch].float().contiguous()[:, :, None], dt, cpad=8)
+                tok = ops.ncfhw_to_tokens(images[i:i + nb].float().contiguous()[:, :, None], dt, cpad=8)
             outs.append(self.vae.encode_tokens(tok))
         return torch.cat(outs) * VAE_SCALE
 
@@ -252,8 +254,9 @@ class Pose2VideoPipeline:
         _, C, F, h, w = latents.shape
         z = ops.ncfhw_to_tokens((latents * (1.0 / VAE_SCALE)).contiguous(), dt, cpad=8)  # [F,h,w,8]
         frames = []
-        for i in range(0, F, self.vae_batch):
-            y = self.vae.decode_tokens(z[i:i + self.vae_batch].contiguous())
+        nb = min(self.vae_batch, self.vae.max_images(8 * h, 8 * w))
+        for i in range(0, F, nb):
+            y = self.vae.decode_tokens(z[i:i + nb].contiguous())
             frames.append(ops.tokens_to_image(y, y.shape[0], y.shape[1], y.shape[2]))
         return torch.cat(frames).permute(1, 0, 2, 3)[None]
 

@@ -235,6 +235,13 @@ class AutoencoderKL(HipModule):
                                                  (0, 8 - lc, 0, 8 - lc)).to(dt).contiguous(),  # [8,8], zero pad rows/cols
                     pq_b=pad_vec(self.post_quant_conv.bias, 8))
 
+    def max_images(self, H, W):
+        """Images of H x W pixels one launch group may hold: the largest activation (block_out_channels[1] channels at
+        full resolution, 2 bytes) must stay below the 2 GiB operand limit of mimo_conv2d (32-bit buffer offsets)."""
+        boc = self.config.block_out_channels
+        per_image = H * W * max(boc[0], boc[min(1, len(boc) - 1)]) * 2
+        return max(1, (2 ** 31 - 1) // per_image)
+
     # ---- token-level API used by the pipeline ----
     def encode_tokens(self, x_tok):
         """x_tok: half [n,H,W,8] (RGB in [-1,1] + 5 zero channels) -> posterior mean, fp32 tokens [n,H/8,W/8,4]."""

@@ -30,7 +30,7 @@ def timeit(fn, iters=10, warm=3):
 
 def ab_table(settings, dt, dev, n):
     """Interleaved A/B: every shape is timed under every knob setting in turn, 3 rounds, best median kept."""
-    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE", "MIMO_GEMM_BM", "MIMO_GEMM_PERSIST")
+    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE", "MIMO_GEMM_BM", "MIMO_GEMM_PERSIST", "MIMO_CONV_PREFETCH")
     cases = []
     for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (8, 2560, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
@@ -89,7 +89,8 @@ def attn_ab(dt, dev):
     """Spatial attention d = 40: legacy kernel vs attn40_kernel program orders (tune build: MIMO_ATTN40_* knobs)."""
     variants = [("legacy", {"MIMO_ATTN40_LEGACY": "1"}), ("v3 4 waves", {"MIMO_ATTN40_NW": "4"}), ("v3 8 waves", {"MIMO_ATTN40_NW": "8"}),
                 ("v3 4w no-mem", {"MIMO_ATTN40_NW": "4", "MIMO_ATTN40_ABLATE": "1"}),
-                ("v3 8w no-mem", {"MIMO_ATTN40_NW": "8", "MIMO_ATTN40_ABLATE": "1"})]
+                ("v3 4w no-wait", {"MIMO_ATTN40_NW": "4", "MIMO_ATTN40_ABLATE": "2"}),
+                ("v3 4w regstage", {"MIMO_ATTN40_NW": "4", "MIMO_ATTN40_STAGE": "1"})]
     for (N, C, nb) in [(4096, 320, 48), (1024, 320, 48), (9604, 320, 8)]:
         qkv = torch.randn(nb, N, 3 * C, device=dev).to(dt)
         bank = torch.randn(N, 2 * C, device=dev).to(dt)
@@ -98,18 +99,32 @@ def attn_ab(dt, dev):
 
         def mk(env):
             def f():
-                for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE"):
+                for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE", "MIMO_ATTN40_STAGE"):
                     os.environ.pop(kk, None)
                 os.environ.update(env)
                 return ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=nb // 2, q_prescaled=True)
             return f
         fns = [mk(env) for _, env in variants]
         outs = [f().float() for f in fns]
+        # the same work with K / V tiles CONTIGUOUS in memory (head-major [B*heads, N, 40]: a tile DMA is 8 full 128-byte
+        # lines instead of ~20 partial ones of 80 bytes at the 1920-byte token pitch): does the L1 request count matter?
+        qh = torch.randn(nb * 8, N, 40, device=dev).to(dt)
+        kh, vh = torch.randn(nb * 8, N, 40, device=dev).to(dt), torch.randn(nb * 8, N, 40, device=dev).to(dt)
+        bh = torch.randn(N, 80, device=dev).to(dt)
+
+        def contiguous_kv():
+            for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE", "MIMO_ATTN40_STAGE"):
+                os.environ.pop(kk, None)
+            return ops.attention(qh, kh, vh, 1, k2=bh[:, :40], v2=bh[:, 40:], seg2_first_batch=nb * 4, q_prescaled=True)
+        fns.append(contiguous_kv)
+        names = [n for n, _ in variants] + ["v3 head-major"]
+        outs.append(outs[0])
+        contiguous_kv()
         res = med_interleaved(fns)
-        for (name, _), (tmin, tmed), o in zip(variants, res, outs):
+        for name, (tmin, tmed), o in zip(names, res, outs):
             err = float((o - outs[0]).norm() / outs[0].norm())
             print(f"attn N{N} d40 b{nb} {name:13s}: min {tmin*1e3:7.3f} ms med {tmed*1e3:7.3f} ms  {fl/tmin/1e12:7.1f} TF/s  rel-L2 vs legacy {err:.1e}", flush=True)
-    for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE"):
+    for kk in ("MIMO_ATTN40_LEGACY", "MIMO_ATTN40_NW", "MIMO_ATTN40_ABLATE", "MIMO_ATTN40_STAGE"):
         os.environ.pop(kk, None)
 
 
@@ -181,11 +196,14 @@ def main():
         img[..., 3:] = 0
         z = torch.randn(8, 64, 64, 8, device=dev).to(dt)
         z[..., 4:] = 0
-        for name, fn, fl in (("vae.encode 8x512^2", lambda: vae.encode_tokens(img), 8 * 1.1167e12),
-                             ("vae.decode 8x64^2->512^2", lambda: vae.decode_tokens(z), 8 * 2.5145e12),
-                             ("pose_guider 8x512^2", lambda: pg.run_tokens(img), 8 * 0.0147e12)):
-            t = timeit(fn, iters=3, warm=1)
-            print(f"{name}: {t*1e3:8.2f} ms  {fl/t/1e12:7.1f} TF/s (algorithmic)")
+        for max_hw in (ops.COLSTATS_MAX_HW, 1 << 30):  # second pass: GroupNorm column statistics from the conv epilogues at every size
+            ops.COLSTATS_MAX_HW = max_hw
+            print(f"# COLSTATS_MAX_HW = {max_hw}")
+            for name, fn, fl in (("vae.encode 8x512^2", lambda: vae.encode_tokens(img), 8 * 1.1167e12),
+                                 ("vae.decode 8x64^2->512^2", lambda: vae.decode_tokens(z), 8 * 2.5145e12),
+                                 ("pose_guider 8x512^2", lambda: pg.run_tokens(img), 8 * 0.0147e12)):
+                t = timeit(fn, iters=3, warm=1)
+                print(f"{name}: {t*1e3:8.2f} ms  {fl/t/1e12:7.1f} TF/s (algorithmic)", flush=True)
         return
     # --- 3x3 convs (n, hw, cin, cout)
     for (hw, cin, cout) in [] if (a.norms or a.attn) else [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320), (16, 2560, 1280)]:

@@ -20,7 +20,7 @@ def per_kernel(path, counter):
             continue
         k = r["Kernel_Name"]
         fam = "gemm_kernel" if ("gemm_kernel" in k or "gemm_dense_persist_kernel" in k or "splitk_reduce" in k) else \
-              "attn_kernel" if "attn_kernel" in k and "temporal" not in k else None
+              "attn_kernel" if ("attn_kernel" in k or "attn40_kernel" in k) and "temporal" not in k else None
         if fam:
             tot[fam] += float(r["Counter_Value"])
             n[fam].add(r["Dispatch_Id"])
