@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.cuh"
+#include "gemm_stream.cuh"
 
 namespace {
 
@@ -99,7 +100,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- epilogue of one output tile: lane holds out[m = M0 + .. + li][n = N0 + .. + 4*lg + r], r = 0..3 ----
-template <int DT, int NR, int MT, int BM>
+template <int DT, int NR, int MT, int BM, bool PAIR = true>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0, const int N0,
                                               const int wm, const int wn, const int lg, const int li,
                                               const unsigned ysplit) {
@@ -115,6 +116,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
   const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
   const int n_out = geglu ? g.N / 2 : g.N;
   const unsigned esz_o = out_f32 ? 4u : 2u, esz_r = res_f32 ? 4u : 2u;
+  const bool pair16 = (n_out & 7) == 0;  // half output in 16-byte stores (lane exchange below)
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
       (char*)g.out + ((int64_t)ysplit * g.M + M0) * g.ldo * esz_o, 0,
       (int)(((rows_valid - 1) * g.ldo + n_out) * esz_o), 0x00020000);
@@ -202,6 +204,82 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
       }
     }
   };
+  // half output in 16-byte stores.  A lane holds 4 consecutive columns of a row; the two rows of a pair of MFMA tiles are
+  // exchanged between neighbouring 16-lane rows (v_permlane16_swap) so that every lane stores 8 consecutive columns of
+  // ONE row: the store path retires about one wave-instruction per 70 cycles whatever its width, and 8-byte stores
+  // capped the short-K GEMMs near 7 B/clk per CU.  Operands are fetched per 16-column group, just in time (registers).
+  auto epilogue_pair = [&](auto has_res_c, auto has_imgb_c, auto geglu_c) {
+    constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
+    constexpr bool HAS_IMGB = decltype(has_imgb_c)::value != 0;
+    constexpr bool GEGLU = decltype(geglu_c)::value != 0;
+    static_assert(MT % 2 == 0, "rows are processed in pairs of MFMA tiles");
+    // every bias load is issued before the first store: vmcnt retires in order, a load behind a store would wait for
+    // the store's acknowledgement
+    f32x4 bv[NR];
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const int n = N0 + col0 + ni * 16;
+      bv[ni] = ld4(r_bias, n < g.N ? (unsigned)n * 4u : OOB);
+    }
+    // rows outer, column groups inner: consecutive stores fill the two rows of the pair left to right
+#pragma unroll
+    for (int mi0 = 0; mi0 < MT; mi0 += 2) {
+#pragma unroll
+      for (int ni = 0; ni < NR; ni += (GEGLU ? 2 : 1)) {
+        if (GEGLU && ni + 1 >= NR) break;
+        const int n = N0 + col0 + ni * 16;
+        const bool okc = n < g.N;
+        const int nt = GEGLU ? (N0 + wn * 16 * NR + ni * 16) / 2 : N0 + wn * 16 * NR + ni * 16;  // first output column of the tile
+        const unsigned c8 = (unsigned)(nt + 4 * (lg & ~1));
+        f32x4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int mi = mi0 + u;
+          const unsigned row = (unsigned)(row0 + mi * 16);
+          v[u] = acc[ni][mi] + bv[ni];
+          if (HAS_IMGB)
+            v[u] += ld4(r_imgb, okc ? ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + (unsigned)n * 4u : OOB);
+          if (GEGLU) {
+            const int ng = ni + 1 < NR ? ni + 1 : ni;
+            const f32x4 gt = acc[ng][mi] + bv[ng];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[u][r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
+          }
+          if (do_silu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[u][r] = silu_f(v[u][r]);
+          }
+          if (HAS_RES) {
+            if (res_f32) {
+              v[u] += ld4(r_res, okc ? (row * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
+            } else {
+              const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc ? (row * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+              v[u] += (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
+                              HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
+            }
+          }
+          v[u] *= g.out_scale;
+        }
+        const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(v[0][0], v[0][1]), pack2<DT>(v[1][0], v[1][1]), false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(v[0][2], v[0][3]), pack2<DT>(v[1][2], v[1][3]), false, false);
+        const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+        // even 16-lane rows: row mi0, columns 4 lg .. 4 lg + 7; odd rows: row mi0 + 1, columns 4 (lg - 1) ..
+        const unsigned row = (unsigned)(row0 + (mi0 + (lg & 1)) * 16);
+        const unsigned ooff = (int)c8 < n_out ? (row * (unsigned)g.ldo + c8) * 2u : OOB;  // n_out % 8 == 0
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_out, ooff, 0, 0);
+      }
+    }
+  };
+  // (GEGLU and the 16-wave tiles keep the per-row form: 128 registers per wave, the paired form spills there)
+  if constexpr (PAIR) {
+    if (!out_f32 && pair16 && !geglu) {
+      if (g.res && g.img_bias) epilogue_pair(IC<1>{}, IC<1>{}, IC<0>{});
+      else if (g.res) epilogue_pair(IC<1>{}, IC<0>{}, IC<0>{});
+      else if (g.img_bias) epilogue_pair(IC<0>{}, IC<1>{}, IC<0>{});
+      else epilogue_pair(IC<0>{}, IC<0>{}, IC<0>{});
+      return;
+    }
+  }
   if (geglu) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
   else if (g.res && g.img_bias) epilogue(IC<1>{}, IC<1>{}, IC<0>{});
   else if (g.res) epilogue(IC<1>{}, IC<0>{}, IC<0>{});
@@ -474,14 +552,21 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
     const unsigned n = (unsigned)(col0 + ni * 16);
     const f32x4 gm = ld4(r_gam, n * 4u), bt = ld4(r_bet, n * 4u) + ld4(r_pe, g.ln_pe ? n * 4u : OOB);
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const unsigned row = (unsigned)(row0 + mi * 16);
-      f32x4 y;
+    for (int mi = 0; mi < MT; mi += 2) {  // 16-byte stores through the lane exchange of tile_epilogue
+      u32x2 o[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[ni][mi][r] - mean[mi]) * rstd[mi], gm[r], bt[r]);
-      u32x2 o;
-      o.x = pack2<DT>(y[0], y[1]); o.y = pack2<DT>(y[2], y[3]);
-      __builtin_amdgcn_raw_buffer_store_b64(o, r_ln, (row * (unsigned)g.N + n) * 2u, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[ni][mi + u][r] - mean[mi + u]) * rstd[mi + u], gm[r], bt[r]);
+        o[u].x = pack2<DT>(y[0], y[1]); o[u].y = pack2<DT>(y[2], y[3]);
+      }
+      const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+      const u32x4 o16 = {sx[0], sy[0], sx[1], sy[1]};
+      const unsigned row = (unsigned)(row0 + (mi + (lg & 1)) * 16);
+      const unsigned c8 = (unsigned)(wn * 16 * NR + ni * 16 + 4 * (lg & ~1));
+      __builtin_amdgcn_raw_buffer_store_b128(o16, r_ln, (row * (unsigned)g.N + c8) * 2u, 0, 0);
     }
   }
 }
@@ -833,7 +918,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
         done = true;
       }
     }
-    if (!done) tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
+    if (!done) tile_epilogue<DT, NR, MT, BM, (WM * WN <= 8)>(g, acc, M0, N0, wm, wn, lg, li, blockIdx.y);
   }
 #ifdef MIMO_TUNE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -998,7 +1083,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
     if constexpr (EPI == 1) {
       tile_epilogue_ln<DT, NR, MT, BM, WN>(g, acc, M0, wm, wn, lg_, li_, reinterpret_cast<float*>(&smem[2 * STAGE]));
     } else {
-      tile_epilogue<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
+      tile_epilogue<DT, NR, MT, BM, (WM * WN <= 8)>(g, acc, M0, N0, wm, wn, lg_, li_, 0u);
     }
     MIMO_TRACE(g, tr, 6);
   }
@@ -1284,6 +1369,18 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
   if (ab >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // 32-bit offsets; 2 GiB keeps OOBA + soffset out of range
   g.a_bytes = (unsigned)ab; g.a2_bytes = 0; g.w_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
+  // level-0 token linears (K = 320, plain half output or GEGLU): A in registers, W streamed (gemm_stream.hip)
+  if (tune_env("MIMO_GEMM_STREAM", 1) && mimo_stream::supported(M, N, K) && !residual && !img_bias && !g.colstats && !g.ln_out &&
+      !(flags & (MIMO_EPI_SILU | MIMO_EPI_OUT_F32)) && out_scale == 1.f && (lda & 7) == 0 && (ldo & 3) == 0 &&
+      aligned16(A) && aligned16(W) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {
+    mimo_stream::Args a{};
+    a.A = g.A; a.W = g.W; a.out = out; a.bias = bias; a.lda = lda; a.ldo = ldo; a.M = M; a.N = N;
+    a.geglu = (flags & MIMO_EPI_GEGLU) ? 1 : 0;
+#ifdef MIMO_TUNE
+    a.dbg = tune_env("MIMO_GEMM_TRACE", 0) ? trace_buf() : nullptr;
+#endif
+    return mimo_stream::launch(dtype, a, cus_(), st);
+  }
   if (dtype == MIMO_F16) return launch<MIMO_F16, 0>(g, st);
   if (dtype == MIMO_BF16) return launch<MIMO_BF16, 0>(g, st);
   return MIMO_EDTYPE;

@@ -78,6 +78,42 @@ def test_gemm_geglu(dev, dtype, M, dim):
     assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [256 * 64, 256 * 70 + 37])
+def test_gemm_stream_k320(dev, dtype, M):
+    """K = 320 over many rows (the level-0 QKV / GEGLU FF1 linears) takes the A-in-registers, W-streamed kernel
+    (gemm_stream.hip): plain half output with and without bias, a row-strided A view, a wider output row stride, GEGLU;
+    ragged last panel; the result must also equal the tiled kernel's (same products, fp32 accumulation)."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_geglu
+    K = 320
+    big = rnd((M, K + 64), dev, dtype, 1)
+    a = big[:, 32:32 + K].contiguous()
+    w = rnd((960, K), dev, dtype, 2, K ** -0.5)
+    b = rnd((960,), dev, torch.float32, 3)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w)
+    assert out.dtype == dtype and rel_l2(out.float(), ref) < OUT_TOL[dtype]
+    out = ops.gemm(a, w, bias=b)
+    assert rel_l2(out.float(), ref + b) < OUT_TOL[dtype]
+    # strided A view (lda = K + 64) and an output view with a wider row stride
+    ob = torch.zeros((M, 1024), device=dev, dtype=dtype)
+    ops.gemm(big[:, 64:64 + K], w, bias=b, out=ob[:, :960])
+    assert rel_l2(ob[:, :960].float(), big[:, 64:64 + K].float() @ w.float().t() + b) < OUT_TOL[dtype]
+    assert float(ob[:, 960:].abs().max()) == 0.0
+    # the tiled kernel (fp32 output keeps it off the streaming path) rounds to the same halfs
+    tiled = ops.gemm(a, w, bias=b, out_f32=True).to(dtype)
+    assert float((ops.gemm(a, w, bias=b).float() - tiled.float()).abs().max()) <= 2 ** -7 * float(tiled.float().abs().max())
+    # GEGLU
+    inner = 1280
+    wg = rnd((2 * inner, K), dev, dtype, 4, K ** -0.5)
+    bg = rnd((2 * inner,), dev, torch.float32, 5, 0.1)
+    wp, bp = pack_geglu(wg, bg, dtype)
+    out = ops.gemm(a, wp, bias=bp, geglu=True)
+    h = a.float() @ wg.float().t() + bg
+    assert out.shape == (M, inner) and rel_l2(out.float(), h[:, :inner] * F.gelu(h[:, inner:])) < OUT_TOL[dtype]
+
+
 CONV_CASES = [
     # n, H, W, Cin, Cout, ks, stride, pad(t,l), out_hw, upsample_to
     (2, 16, 16, 64, 160, 3, 1, None, None, None),
