@@ -1,0 +1,38 @@
+"""A/B of one denoising forward (CFG batch of 2 x 24 latent frames) over settings of mimo_amd.ops module knobs:
+  python tools/ab_forward.py CHUNK_TOKENS=0 CHUNK_TOKENS=65536 [--size 512]
+Each setting is timed three times, interleaved; prints the per-setting best and the gemm/attention family times."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from mimo_amd import ops  # noqa: E402
+
+
+def main():
+    size = 512
+    args = [a for a in sys.argv[1:]]
+    if "--size" in args:
+        i = args.index("--size")
+        size = int(args[i + 1])
+        del args[i:i + 2]
+    settings = [dict(kv.split("=") for kv in a.split(",")) for a in args] or [{}]
+    dev = torch.device("cuda:0")
+    pipe = bench.build_pipeline(dev, torch.float16)
+    best = [None] * len(settings)
+    for rnd in range(3):
+        for i, st in enumerate(settings):
+            for k, v in st.items():
+                setattr(ops, k, type(getattr(ops, k))(v))
+            t, fl, n, fam = bench.measure_forward(pipe, dev, torch.float16, size, iters=3)
+            if best[i] is None or t < best[i][0]:
+                best[i] = (t, n, fam)
+    for st, (t, n, fam) in zip(settings, best):
+        print(f"{st}: forward {t*1e3:.2f} ms, {n} launches; " +
+              "; ".join(f"{k} {d['ms']:.2f} ms / {d['launches']}" for k, d in fam.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
