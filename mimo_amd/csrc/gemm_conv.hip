@@ -1377,6 +1377,7 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
     a.geglu = (flags & MIMO_EPI_GEGLU) ? 1 : 0;
 #ifdef MIMO_TUNE
     a.dbg = tune_env("MIMO_GEMM_TRACE", 0) ? trace_buf() : nullptr;
+    a.ablate = tune_env("MIMO_STREAM_ABLATE", 0);
 #endif
     return mimo_stream::launch(dtype, a, cus_(), st);
   }

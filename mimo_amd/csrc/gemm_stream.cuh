@@ -14,6 +14,7 @@ struct Args {
   int N;
   int geglu;
   unsigned long long* dbg;  // tune build trace buffer or null
+  int ablate;               // tune build timing experiments (results are wrong): 1 no B-fragment reads, 2 no stores, 3 no DMA, 4 no MFMA
 };
 
 // true when the streaming kernel implements this problem (K == 320, N % 64 == 0, N <= 4096, enough rows to fill the chip)

@@ -34,17 +34,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #ifdef MIMO_TUNE
+// two tracers: thread 0 (wave 0, stores after its MFMAs) fills entries [0, 2000), thread 256 (wave 4, stores first) [2000, 4000)
 #define STREAM_TRACE(g, idx, tag)                                                                                  \
   do {                                                                                                             \
-    if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0 && (idx) < 4000u)                                           \
-      (g).dbg[(idx)++] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+    if ((g).dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (idx) < 2000u)                                   \
+      (g).dbg[(threadIdx.x >> 8) * 2000u + (idx)++] =                                                              \
+          ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull);              \
   } while (0)
-#define STREAM_TRACE_REAL(g, idx, tag)                                                                                \
-  do {                                                                                                                \
-    if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0 && (idx) < 4000u)                                              \
-      (g).dbg[(idx)++] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull); \
+#define STREAM_TRACE_REAL(g, idx, tag)                                                                             \
+  do {                                                                                                             \
+    if ((g).dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (idx) < 2000u)                                   \
+      (g).dbg[(threadIdx.x >> 8) * 2000u + (idx)++] =                                                              \
+          ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull);          \
   } while (0)
+#define STREAM_ABLATE(g, n) ((g).ablate == (n))
 #else
+#define STREAM_ABLATE(g, n) false
 #define STREAM_TRACE(g, idx, tag) do { (void)(idx); } while (0)
 #define STREAM_TRACE_REAL(g, idx, tag) do { (void)(idx); } while (0)
 #endif
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
     const unsigned dst = smem_base + ld_s * (unsigned)TILE_B + wave_u * (NDMA * 1024u);
     const unsigned soff = ld_j * (unsigned)TILE_B;
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma(live ? w_voff[i] : OOBA, soff, dst + i * 1024u);
+    for (int i = 0; i < NDMA; ++i) dma(live && !STREAM_ABLATE(g, 3) ? w_voff[i] : OOBA, soff, dst + i * 1024u);
     ++ld_t;
     ld_j = ld_j + 1 == (unsigned)NT ? 0u : ld_j + 1;
     ld_s = ld_s + 1 == (unsigned)NST ? 0u : ld_s + 1;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
 #pragma unroll
       for (int k = 0; k < 16 / RPI; ++k) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(pr_ + k * RPI * PITCH);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rO, oj + (unsigned)(mi * 16 / RPI + k) * o_rpi, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rO, STREAM_ABLATE(g, 2) ? OOBA : oj + (unsigned)(mi * 16 / RPI + k) * o_rpi, 0, 0);
       }
     }
   };
@@ -224,7 +229,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
         epilogue(acc, rO_prev, j_prev);
         rO_prev = rO;
         j_prev = j;
+        STREAM_TRACE(g, tr, 10);
         issue_next();  // the DMA issue (about 100 cycles a piece) of one wave also runs under the other wave's MFMAs
+        STREAM_TRACE(g, tr, 9);
       }
       const unsigned sq = cs * (unsigned)(TILE_B / 16);  // 16-byte index of the stage
 #pragma unroll
@@ -237,12 +244,22 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
       auto ldb = [&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         const unsigned q = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 8);  // + (ks >> 1) * 128 bytes
+        if (STREAM_ABLATE(g, 1)) {
 #pragma unroll
-        for (int ni = 0; ni < NR; ++ni) fb[ks][ni] = smem[q + ni * (16 * ROWB / 16)];  // 16 rows apart
+          for (int ni = 0; ni < NR; ++ni) fb[ks][ni] = fa[ni & 1][ks];
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) fb[ks][ni] = smem[q + ni * (16 * ROWB / 16)];  // 16 rows apart
+        }
       };
       auto kstep = [&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if constexpr (ks + PF < KS) ldb(IC<ks + PF>{});
+        if (STREAM_ABLATE(g, 4)) {
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) acc[ni][0][0] += __builtin_bit_cast(float, fb[ks][ni].x);
+          return;
+        }
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni)
 #pragma unroll
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
       STREAM_TRACE(g, tr, 5);
       if (!late_store) {
         issue_next();
+        STREAM_TRACE(g, tr, 9);
         epilogue(acc, rO, j);
       }
       STREAM_TRACE(g, tr, 6);

@@ -30,7 +30,7 @@ def timeit(fn, iters=10, warm=3):
 
 def ab_table(settings, dt, dev, n):
     """Interleaved A/B: every shape is timed under every knob setting in turn, 3 rounds, best median kept."""
-    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE", "MIMO_GEMM_BM", "MIMO_GEMM_PERSIST", "MIMO_GEMM_STREAM")
+    knobs = ("MIMO_GEMM_CFG", "MIMO_GEMM_STAGGER", "MIMO_CONV_TAP_INNER", "MIMO_GEMM_SPLITK", "MIMO_GEMM_ABLATE", "MIMO_GEMM_BM", "MIMO_GEMM_PERSIST", "MIMO_GEMM_STREAM", "MIMO_STREAM_ABLATE")
     cases = []
     for (hw, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (8, 2560, 1280), (64, 960, 320), (16, 2560, 1280)]:
         x = torch.randn(n, hw, hw, cin, device=dev).to(dt)
