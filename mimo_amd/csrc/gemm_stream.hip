@@ -55,6 +55,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 
 constexpr int MAXN = 4096;  // bias image in LDS
+constexpr int NW = 8;        // waves per block (two per SIMD; 12 = three per SIMD leaves the compiler no registers to prefetch
+                             // B fragments under its 168-register cap: every MFMA pair then waits for its own LDS read, 2.5x slower)
+constexpr int BM_ROWS = 32 * NW;
 
 template <int V>
 struct IC {
@@ -62,22 +65,23 @@ struct IC {
 };
 
 template <int DT, int KS, bool GEGLU>
-__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
+__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_stream_kernel(const Args g) {
   constexpr int K = 32 * KS;
   constexpr int ROWB = K * 2;                // bytes of one W row
-  constexpr int BN = 64, BM = 256, NST = 3;
+  constexpr int BN = 64, BM = BM_ROWS, NST = 3;
   constexpr int TILE_B = BN * ROWB;          // 40 KB at K = 320
-  constexpr int NDMA = TILE_B / (8 * 1024);  // 1-KB DMAs per wave per tile
+  constexpr int NDMA = NW == 8 ? 5 : 4;      // 1-KB DMAs per tile of the waves that load (waves 0 .. NLOADW - 1)
+  constexpr int NLOADW = TILE_B / (NDMA * 1024);
   constexpr int MT = 2, NR = 4;              // wave tile: 32 rows x 64 packed columns
   constexpr int OC = GEGLU ? 32 : 64;        // output columns of a wave per step
   constexpr int NSTORE = GEGLU ? 2 : 4;      // 16-byte stores per wave per step
   constexpr int PITCH = OC * 2 + 16;         // bytes per row of the wave's transposition patch (16 rows)
   constexpr int PATCH_B = 16 * PITCH;
   constexpr unsigned OOBA = 0x80000000u;
-  static_assert(TILE_B % (8 * 1024) == 0 && K % 64 == 0, "tile must be whole DMAs, rows whole 128-byte groups");
+  static_assert(TILE_B % (NDMA * 1024) == 0 && NLOADW <= NW && K % 64 == 0, "tile must be whole DMAs, rows whole 128-byte groups");
   static_assert(NDMA + 2 * NSTORE < 64, "vmcnt is 6 bits");
-  static_assert(NST * TILE_B + MAXN * 4 + 8 * PATCH_B <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) uint4 smem[(NST * TILE_B + MAXN * 4 + 8 * PATCH_B) / 16];  // ONE LDS object
+  static_assert(NST * TILE_B + MAXN * 4 + NW * PATCH_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) uint4 smem[(NST * TILE_B + MAXN * 4 + NW * PATCH_B) / 16];  // ONE LDS object
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
   float* const bias_lds = reinterpret_cast<float*>(&smem[NST * TILE_B / 16]);
   constexpr unsigned PATCH_Q = (NST * TILE_B + MAXN * 4) / 16;  // 16-byte index of patch 0
 
-  for (int n = tid; n < g.N; n += 512) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+  for (int n = tid; n < g.N; n += 64 * NW) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
 
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -116,13 +120,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
   const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
   const unsigned total = my_panels * (unsigned)NT;
   unsigned ld_t = 0, ld_j = 0, ld_s = 0;
+  const bool loader = wave_u < (unsigned)NLOADW;  // 40 pieces per tile over the first NLOADW waves
   auto issue_next = [&]() {
-    const bool live = ld_t < total;
+    ++ld_t;
+    if (!loader) return;
+    const bool live = ld_t <= total;
     const unsigned dst = smem_base + ld_s * (unsigned)TILE_B + wave_u * (NDMA * 1024u);
     const unsigned soff = ld_j * (unsigned)TILE_B;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) dma(live && !STREAM_ABLATE(g, 3) ? w_voff[i] : OOBA, soff, dst + i * 1024u);
-    ++ld_t;
     ld_j = ld_j + 1 == (unsigned)NT ? 0u : ld_j + 1;
     ld_s = ld_s + 1 == (unsigned)NST ? 0u : ld_s + 1;
   };
@@ -220,8 +226,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
       STREAM_TRACE(g, tr, 2);
       // this wave's part of the tile has landed: memory operations issued after DMA(t) are
       //   early waves: stores(t-2) DMA(t+1) stores(t-1);   late waves: stores(t-2) DMA(t+1)
-      if (late_store) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NSTORE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2 * NSTORE) : "memory");
+      if (loader) {
+        if (late_store) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NSTORE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 2 * NSTORE) : "memory");
+      }  // (waves without pieces of the tile wait for nothing: the barrier below covers them)
       STREAM_TRACE(g, tr, 7);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all parts landed; stage (cs + 2) % 3 is free
       STREAM_TRACE(g, tr, 3);
@@ -287,19 +295,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const Args g) {
 
 }  // namespace
 
-bool supported(int64_t M, int N, int K) { return K == 320 && N % 64 == 0 && N >= 640 && N <= MAXN && M >= 256 * 64; }
+bool supported(int64_t M, int N, int K) { return K == 320 && N % 64 == 0 && N >= 640 && N <= MAXN && M >= (int64_t)BM_ROWS * 64; }
 
 int launch(int dtype, const Args& a, int cus, hipStream_t st) {
   if (!supported(a.M, a.N, 320)) return MIMO_EINVAL;
-  const int64_t npanels = (a.M + 255) / 256;
+  const int64_t npanels = (a.M + BM_ROWS - 1) / BM_ROWS;
   if (npanels > 0x7fffffff) return MIMO_EINVAL;
   const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
   if (dtype == MIMO_F16) {
-    if (a.geglu) hipLaunchKernelGGL((gemm_stream_kernel<MIMO_F16, 10, true>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm_stream_kernel<MIMO_F16, 10, false>), dim3(grid), dim3(512), 0, st, a);
+    if (a.geglu) hipLaunchKernelGGL((gemm_stream_kernel<MIMO_F16, 10, true>), dim3(grid), dim3(64 * NW), 0, st, a);
+    else hipLaunchKernelGGL((gemm_stream_kernel<MIMO_F16, 10, false>), dim3(grid), dim3(64 * NW), 0, st, a);
   } else if (dtype == MIMO_BF16) {
-    if (a.geglu) hipLaunchKernelGGL((gemm_stream_kernel<MIMO_BF16, 10, true>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm_stream_kernel<MIMO_BF16, 10, false>), dim3(grid), dim3(512), 0, st, a);
+    if (a.geglu) hipLaunchKernelGGL((gemm_stream_kernel<MIMO_BF16, 10, true>), dim3(grid), dim3(64 * NW), 0, st, a);
+    else hipLaunchKernelGGL((gemm_stream_kernel<MIMO_BF16, 10, false>), dim3(grid), dim3(64 * NW), 0, st, a);
   } else {
     return MIMO_EDTYPE;
   }
