@@ -45,7 +45,7 @@ def report(name, fn, flops):
     ms = st.elapsed_time(en)
     tr = fetch()
     if not tr:
-        print(f"{name}: no trace (kernel without trace points)")
+        print(f"{name}: launch {ms*1e3:.0f} us ({flops/ms/1e9:.0f} TF/s); no trace (kernel without trace points)")
         return
     real = [t for tag, t in tr if tag in (0xfe, 0xff)]
     cyc = [(tag, t) for tag, t in tr if tag not in (0xfe, 0xff)]
@@ -94,6 +94,15 @@ def main():
         report(f"gemm M{M} N{N} K{K}", lambda: ops.gemm(A, W), 2 * M * N * K)
         if N == 320:
             report(f"gemm+res32 M{M} N{N} K{K}", lambda: ops.gemm(A, W, residual=R, out_f32=True), 2 * M * N * K)
+    # the LayerNorm-fused C x C linears of level 0 (BM = 128 persistent kernel, whole rows per tile)
+    M, C = 196608, 320
+    A = torch.randn(M, C, device=dev).to(dt)
+    W = (torch.randn(C, C, device=dev) * 0.05).to(dt)
+    R = torch.randn(M, C, device=dev)
+    b = torch.zeros(C, device=dev)
+    ln = dict(gamma=torch.ones(C, device=dev), beta=torch.zeros(C, device=dev), eps=1e-5)
+    report("gemm+ln M196608 N320 K320 (proj_in)", lambda: ops.gemm(A, W, bias=b, out_f32=True, ln=ln), 2 * M * C * C)
+    report("gemm+res32+ln M196608 N320 K320 (to_out)", lambda: ops.gemm(A, W, bias=b, residual=R, out_f32=True, ln=ln), 2 * M * C * C)
     for (M, dim) in [(196608, 320), (49152, 640), (12288, 1280)]:
         A = torch.randn(M, dim, device=dev).to(dt)
         wp, bp = pack_geglu(torch.randn(8 * dim, dim, device=dev) * 0.02, torch.zeros(8 * dim, device=dev), dt)
