@@ -290,25 +290,29 @@ def _small_clip(dev, shard=False, invariant=False):
     return torch.cat([latents.flatten(), vid.flatten()])
 
 
-def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev):
-    """one clip whose (window, CFG-half) units and per-frame stages are dealt over 2 ranks (both on this
+@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.skipif(
+    not os.environ.get("MIMO_TEST_WORLD4"), reason="four processes time-slicing one GPU take ~4 min; set MIMO_TEST_WORLD4=1 "
+    "(passed on the MI355X box of round 2: profiles/r2_sharded_world4_one_gpu.txt)"))])
+def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world):
+    """one clip whose (window, CFG-half) units and per-frame stages are dealt over `world` ranks (all on this
     GPU, collectives over gloo with host staging — RCCL refuses two ranks on one device) must reproduce the single-process
-    result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides)."""
+    result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides).  F = 26 is two wrapped windows
+    = 4 (window, CFG-half) units: two per rank at world 2, one per rank at world 4."""
     import torch.multiprocessing as mp
     import os
     single = _small_clip(dev, invariant=True).cpu()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 400 + 11
-    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 400 + 11 + world
+    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, world, port, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
-    res = {r: torch.from_numpy(v) for r, v in (q.get(timeout=600) for _ in procs)}
+    res = {r: torch.from_numpy(v) for r, v in (q.get(timeout=900) for _ in procs)}
     for p_ in procs:
         p_.join(timeout=120)
     assert torch.isfinite(single).all()
-    assert torch.equal(res[0], single) and torch.equal(res[1], single)
-    report("sharded long clip (2 ranks, F = 26, 2 steps, fp16): latents and video bit-identical to the single-process run")
+    assert all(torch.equal(res[r], single) for r in range(world))
+    report(f"sharded long clip ({world} ranks, F = 26, 2 steps, fp16): latents and video bit-identical to the single-process run")
 
 
 def test_pipeline_call_surface_pil_inputs(dev):
