@@ -1,0 +1,91 @@
+"""Experiment: do two half-batch denoising forwards on two HIP streams overlap better than one batched forward?
+One CFG step = uncond half + cond half (24 frames each).  Times, on one GPU:
+  (a) the batched b = 2 forward (what the pipeline runs),
+  (b) two b = 1 forwards back to back on one stream,
+  (c) the same two forwards on two streams concurrently.
+(Both halves use the cond configuration here — bank attached — so (b)/(c) do slightly more attention work than (a).)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from mimo_amd import ops  # noqa: E402
+from mimo_amd.modules import Ctx, EarlyExit  # noqa: E402
+from mimo_amd.unet import ReferenceAttentionControl  # noqa: E402
+
+
+def main():
+    dev, dtype, size = torch.device("cuda:0"), torch.float16, 512
+    pipe = bench.build_pipeline(dev, dtype)
+    h = size // 8
+    unet, refu = pipe.denoising_unet, pipe.reference_unet
+    g = torch.Generator(device="cpu").manual_seed(7)
+    writer = ReferenceAttentionControl(refu, mode="write", do_classifier_free_guidance=True)
+    reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=True)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)]).to(dev)
+    rctx = Ctx(dtype, 1, 1)
+    rctx.stop_after = writer.last_block()
+    try:
+        refu.run_tokens(torch.randn(1, h, h, 8, generator=g).to(dev).to(dtype), 0, ehs[1:], 1, 1, None, rctx)
+    except EarlyExit:
+        pass
+    reader.update(writer)
+    x = torch.randn(48, h, h, 8, generator=g).to(dev).to(dtype)
+    pose = torch.randn(48, h, h, 320, generator=g).to(dev)
+    xs, poses = (x[:24].contiguous(), x[24:].contiguous()), (pose[:24].contiguous(), pose[24:].contiguous())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def batched():
+        unet.run_tokens(x, 499, ehs, 2, 24, pose)
+
+    def sequential():
+        for i in range(2):
+            unet.run_tokens(xs[i], 499, ehs[1:], 1, 24, poses[i])
+
+    def concurrent():
+        cur = torch.cuda.current_stream()
+        for s in (s1, s2):
+            s.wait_stream(cur)
+        for i, s in enumerate((s1, s2)):
+            with torch.cuda.stream(s):
+                unet.run_tokens(xs[i], 499, ehs[1:], 1, 24, poses[i])
+        for s in (s1, s2):
+            cur.wait_stream(s)
+
+    def two_batched_seq():
+        batched()
+        batched()
+
+    def two_batched_conc():
+        cur = torch.cuda.current_stream()
+        for s in (s1, s2):
+            s.wait_stream(cur)
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                unet.run_tokens(x, 499, ehs, 2, 24, pose)
+        for s in (s1, s2):
+            cur.wait_stream(s)
+
+    with ops.split_k(False):
+        print(f"two windows (b = 2 each): sequential {timed(two_batched_seq):.2f} ms | on two streams {timed(two_batched_conc):.2f} ms", flush=True)
+    with ops.split_k(False):  # the split-K workspace is shared: not safe across concurrent streams
+        for rnd in range(2):
+            print(f"round {rnd}: batched b=2 {timed(batched):.2f} ms | two b=1 sequential {timed(sequential):.2f} ms | "
+                  f"two b=1 on two streams {timed(concurrent):.2f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
