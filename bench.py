@@ -280,6 +280,8 @@ def main():
     ap.add_argument("--shard-windows", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the denoising forward as a captured hipGraph "
                     "(measured neutral: the launch queue never runs dry, so eager launches are the default)")
+    ap.add_argument("--window-streams", type=int, default=None, help="HIP streams for the independent windows of a step "
+                    "(default: the pipeline's setting, 2; 1 = one stream; only clips with > 24 frames have several windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 sub-record (one extra clip + one forward)")
     ap.add_argument("--cpu-baseline-only", type=float, default=0.0, help=argparse.SUPPRESS)  # child mode: clip FLOPs
@@ -306,6 +308,8 @@ def main():
     frames = a.frames * (world if a.shard_windows else 1)
     pipe.shard_windows = a.shard_windows and world > 1
     pipe.use_graphs = a.graphs and not pipe.shard_windows
+    if a.window_streams is not None:
+        pipe.window_streams = a.window_streams
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
 
     host_video = torch.empty((1, 3, frames, a.size, a.size), dtype=torch.float32, pin_memory=True)

@@ -93,13 +93,33 @@ def split_k_enabled():
 
 
 _WS = {}
+_WS_SLOT = 0
+
+
+class workspace_slot:
+    """Launches issued inside `with workspace_slot(i)` use split-K scratch buffer i of their device.  The pipeline gives each
+    of its concurrent window streams its own slot: two split-K launch pairs on different streams must not share partials."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        global _WS_SLOT
+        self.prev, _WS_SLOT = _WS_SLOT, self.slot
+
+    def __exit__(self, *a):
+        global _WS_SLOT
+        _WS_SLOT = self.prev
+        return False
 
 
 def _workspace(device):
     """Split-K scratch handed to mimo_gemm / mimo_conv2d (include/mimo_hip.h, workspace convention): ONE fp32 buffer
-    per device.  Only the split-K partial-sum launch pair of one call touches it, and the model issues its launches
-    on one stream at a time (during hipGraph capture: the capture stream), so stream order makes sharing safe."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    per (device, workspace slot).  Only the split-K partial-sum launch pair of one call touches it, and launches that
+    share a slot are issued on one stream at a time (during hipGraph capture: the capture stream), so stream order makes
+    sharing safe; concurrent streams take different slots (workspace_slot)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, _WS_SLOT)
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(L.load().mimo_workspace_bytes() // 4, device=device, dtype=torch.float32)
