@@ -389,13 +389,37 @@ class Pose2VideoPipeline:
                                                win_pose[wi].repeat(rep, 1, 1, 1))
                     ops.window_accumulate(pred, idx, acc, counter)
             else:
-                for (wi, half) in my_units:
+                # a rank's units are independent b = 1 forwards: with two or more they run on alternating HIP streams
+                # (two half-batch forwards overlap 15 % better than back to back, profiles/r2_two_stream_forward.txt);
+                # each prediction is handed to the exchange, in unit order, as soon as its stream is done
+                conc = len(my_units) > 1 and self.window_streams > 1
+                main = torch.cuda.current_stream(dev)
+                streams = self._side_streams.setdefault(dev, [torch.cuda.Stream(dev) for _ in range(self.window_streams)]) if conc else [main]
+                if conc:
+                    for s_ in streams:
+                        s_.wait_stream(main)
+                pending = []
+                for k, (wi, half) in enumerate(my_units):
                     idx = win_idx[wi]
-                    lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
-                    x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
-                    e = ehs[half:half + 1] if cfg else ehs
-                    # the gather of this unit's slot starts now and runs under the next unit's forward
-                    exch.put(self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg)))
+                    slot = k % len(streams)
+                    with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot if conc else 0):
+                        lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
+                        x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
+                        e = ehs[half:half + 1] if cfg else ehs
+                        pred = self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg))
+                    pending.append((pred, streams[slot]))
+                    # the oldest pending unit is handed over once every stream has a younger unit queued behind it
+                    if len(pending) == len(streams):
+                        p0, s0 = pending.pop(0)
+                        if conc:
+                            main.wait_stream(s0)
+                            p0.record_stream(main)
+                        exch.put(p0)  # the gather of this unit's slot starts now and runs under the following units
+                for p0, s0 in pending:
+                    if conc:
+                        main.wait_stream(s0)
+                        p0.record_stream(main)
+                    exch.put(p0)
                 allp = exch.finish()
                 for wi, idx in enumerate(win_idx):
                     halves = [allp[(wi, hf)] for hf in ((0, 1) if cfg else (0,))]
