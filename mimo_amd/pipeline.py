@@ -312,6 +312,29 @@ class Pose2VideoPipeline:
             return torch.cat([self.pose_guider.run_tokens(tok[i:i + self.vae_batch].contiguous())
                               for i in range(0, tok.shape[0], self.vae_batch)])
 
+        # reference UNet at t = 0 (pipeline :480-490): only the cond element's banks are ever read, and
+        # everything after the last bank write is dead code -> run b = 1 with early exit.  It is a chain of small (4096-token)
+        # launches that depends only on ref_lat: on the single-GPU path it runs on a side stream under the VAE encode of the
+        # background frames and the pose guider (which fill the chip with large launches).
+        import contextlib
+        from .modules import Ctx, EarlyExit
+        writer = ReferenceAttentionControl(self.reference_unet, mode="write", do_classifier_free_guidance=cfg)
+        reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=cfg)
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if world == 1 and self.window_streams > 1:
+            side = self._side_streams.setdefault(dev, [torch.cuda.Stream(dev) for _ in range(self.window_streams)])[0]
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), ops.workspace_slot(1 if side is not None else 0):
+            ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=self.reference_unet.compute_dtype)
+            ref_tok[..., :C] = ref_lat.to(ref_tok.dtype)
+            rctx = Ctx(self.reference_unet.compute_dtype, 1, 1)
+            rctx.stop_after = writer.last_block()
+            try:
+                self.reference_unet.run_tokens(ref_tok, 0, ehs_c, 1, 1, None, rctx)
+            except EarlyExit:
+                pass
+
         if world > 1:  # one long clip over the ranks: the per-frame stages are sharded too
             bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev), rank, world, self.dist_group).to(dt)
             pose_tok = sharded_frames(pose_fn, pose_images.to(dev), rank, world, self.dist_group)
@@ -319,19 +342,11 @@ class Pose2VideoPipeline:
             bk_tok = self._encode_frames(bk_images.to(dev)).to(dt)             # [F,h,w,4]
             pose_tok = pose_fn(pose_images.to(dev))                            # fp32 [F,h,w,C0]
 
-        # reference UNet at t = 0 (pipeline :480-490): only the cond element's banks are ever read, and
-        # everything after the last bank write is dead code -> run b = 1 with early exit.
-        writer = ReferenceAttentionControl(self.reference_unet, mode="write", do_classifier_free_guidance=cfg)
-        reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=cfg)
-        ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=self.reference_unet.compute_dtype)
-        ref_tok[..., :C] = ref_lat.to(ref_tok.dtype)
-        from .modules import Ctx, EarlyExit
-        rctx = Ctx(self.reference_unet.compute_dtype, 1, 1)
-        rctx.stop_after = writer.last_block()
-        try:
-            self.reference_unet.run_tokens(ref_tok, 0, ehs_c, 1, 1, None, rctx)
-        except EarlyExit:
-            pass
+        if side is not None:
+            main.wait_stream(side)
+            for blk in self.reference_unet.spatial_blocks():  # the banked tensors were allocated on the side stream
+                for bt in blk.bank:
+                    bt.record_stream(main)
         reader.update(writer)
         mark("vae_encode+pose_guider+reference_unet")
 
