@@ -1372,7 +1372,7 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
 #ifndef MIMO_NO_STREAM
 #define MIMO_NO_STREAM 0
 #endif
-  if (!MIMO_NO_STREAM && tune_env("MIMO_GEMM_STREAM", 1) && mimo_stream::supported(M, N, K) && !residual && !img_bias && !g.colstats && !g.ln_out &&
+  if (!MIMO_NO_STREAM && tune_env("MIMO_GEMM_STREAM", 1) && mimo_stream::supported(M, N, K, (flags & MIMO_EPI_NO_SPLITK) != 0) && !residual && !img_bias && !g.colstats && !g.ln_out &&
       !(flags & (MIMO_EPI_SILU | MIMO_EPI_OUT_F32)) && out_scale == 1.f && (lda & 7) == 0 && (ldo & 3) == 0 &&
       aligned16(A) && aligned16(W) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {
     mimo_stream::Args a{};

@@ -17,8 +17,9 @@ struct Args {
   int ablate;               // tune build timing experiments (results are wrong): 1 no B-fragment reads, 2 no stores, 3 no DMA, 4 no MFMA
 };
 
-// true when the streaming kernel implements this problem (K == 320, N % 64 == 0, N <= 4096, enough rows to fill the chip)
-bool supported(int64_t M, int N, int K);
+// true when the streaming kernel implements this problem (K == 320, N % 64 == 0, N <= 4096, and — unless any_m — enough
+// rows to fill the chip)
+bool supported(int64_t M, int N, int K, bool any_m);
 int launch(int dtype, const Args& a, int cus, hipStream_t st);
 
 }  // namespace mimo_stream

@@ -295,10 +295,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_stream_kernel(const Args
 
 }  // namespace
 
-bool supported(int64_t M, int N, int K) { return K == 320 && N % 64 == 0 && N >= 640 && N <= MAXN && M >= (int64_t)BM_ROWS * 64; }
+// any_m: the caller needs the kernel choice to be a function of (N, K) only — batch-invariant runs (MIMO_EPI_NO_SPLITK) must
+// route a b = 1 unit and the b = 2 launch of the same window through the SAME kernel whatever their row counts
+bool supported(int64_t M, int N, int K, bool any_m) {
+  return K == 320 && N % 64 == 0 && N >= 640 && N <= MAXN && M > 0 && (any_m || M >= (int64_t)BM_ROWS * 64);
+}
 
 int launch(int dtype, const Args& a, int cus, hipStream_t st) {
-  if (!supported(a.M, a.N, 320)) return MIMO_EINVAL;
+  if (!supported(a.M, a.N, 320, true)) return MIMO_EINVAL;
   const int64_t npanels = (a.M + BM_ROWS - 1) / BM_ROWS;
   if (npanels > 0x7fffffff) return MIMO_EINVAL;
   const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);

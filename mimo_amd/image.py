@@ -148,8 +148,19 @@ def pil_to_u8(images, device):
     return torch.from_numpy(arr).to(device)
 
 
+class ImageTokens(torch.Tensor):
+    """Marker type of pre-tokenised images (half tokens [n, h, w, 8] from vae_preprocess): the pipeline recognises them by
+    TYPE, not by shape and dtype — a half NCHW batch of width 8 is a legal image input and must not be mistaken for tokens."""
+
+    @staticmethod
+    def wrap(t):
+        return t.as_subclass(ImageTokens)
+
+
 def vae_preprocess(images, height, width, normalize, dtype, device, scale_factor=8):
     """list of PIL images -> half tokens [n, h, w, 8] (channels 3..7 zero), as VaeImageProcessor.preprocess does it."""
+    if len(images) == 0:
+        raise ValueError("vae_preprocess needs at least one image (got an empty list)")
     w, h = width - width % scale_factor, height - height % scale_factor
     groups, out = {}, [None] * len(images)
     for i, im in enumerate(images):  # images of one size share a launch
@@ -163,7 +174,7 @@ def vae_preprocess(images, height, width, normalize, dtype, device, scale_factor
                tok.data_ptr(), ops._stream())
         for j, i in enumerate(idx):
             out[i] = tok[j:j + 1]
-    return torch.cat(out) if len(groups) > 1 else tok
+    return ImageTokens.wrap(torch.cat(out) if len(groups) > 1 else tok)
 
 
 def clip_preprocess(image, device, size=224):

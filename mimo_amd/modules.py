@@ -37,6 +37,7 @@ class Ctx:
         self.dtype = dtype      # MFMA operand dtype (torch.float16 | torch.bfloat16)
         self.b = b              # batch elements (CFG halves)
         self.F = F              # frames per batch element (1 for 2-D models)
+        self.t_emb = None       # half [b, C0]: precomputed sinusoidal timestep embedding (UNetBase.timestep_table) or None
         self.temb = None        # fp32 [b, sum(Cout)]: every ResBlock's time_emb_proj(silu(emb)) at once
         self.attn2 = None       # fp32 [b, sum(C)]: every block's collapsed cross-attention output
         self.stop_after = None  # write mode: block after whose bank write the rest of the graph is dead
@@ -72,6 +73,16 @@ class HipModule(nn.Module):
 
     def _dev(self):
         return next(self.parameters()).device
+
+    def prepack(self, dtype):
+        """Pack every HipModule below (and including) this one NOW, on the current stream.  `packed()` packs lazily on
+        whichever stream is current and publishes the cache entry at once; a consumer on ANOTHER stream would then read
+        buffers whose pack kernels it is not ordered behind, and the buffers would live in that stream's allocator pool.
+        The pipeline calls this on the main stream before it forks side streams (their wait_stream(main) orders them)."""
+        for m in self.modules():
+            if isinstance(m, HipModule) and hasattr(m, "_pack"):
+                m.packed(dtype)
+        return self
 
     def invalidate(self):
         _PACK_EPOCH[0] += 1
@@ -239,7 +250,10 @@ class SpatialTransformerBlock(HipModule):
         """attn2 over ONE key collapses exactly: softmax == 1 -> out = to_out(to_v(e)) independent of the query
         (src/models/attention.py:412-426 with encoder_hidden_states [b,1,768]).  Returns (W_o.W_v fp32 [C,768], b_o)."""
         a2 = self.attn2
-        return a2.to_out[0].weight.detach().float() @ a2.to_v.weight.detach().float(), _f32(a2.to_out[0].bias)
+        # weight preprocessing at pack time, like the repacking: folded once on the HOST in fp64 (no stock-library GEMM
+        # on the device), rounded once to fp32
+        wo, wv = a2.to_out[0].weight.detach().double().cpu(), a2.to_v.weight.detach().double().cpu()
+        return (wo @ wv).float().to(a2.to_out[0].weight.device), _f32(a2.to_out[0].bias)
 
     def ln1(self, dtype):
         """norm1 as the `ln=` argument of the GEMM that produces this block's input (fused into its epilogue)."""

@@ -30,26 +30,82 @@ class Pose2VideoPipelineOutput:
         self.videos = videos
 
 
+# Relative cost of the three kinds of work item of one denoising step, in units of ONE batched window forward (b = 2:
+# uncond + cond rows in one launch sequence).  Measured on one MI355X (profiles/r2_two_stream_forward.txt): batched
+# 83.1 ms; the same window as two b = 1 forwards 108 ms back to back (half-size launches quantise worse), of which the
+# cond half — it attends [self || bank], 1.2518 vs 1.1037 TFLOP per frame — is the heavier one.
+ITEM_COST = {"window": 1.0, "cond": 0.69, "uncond": 0.61}
+
+
+def _item_cost(item):
+    if len(item) == 2:
+        return ITEM_COST["window"]
+    return ITEM_COST["cond"] if item[0][1] == 1 else ITEM_COST["uncond"]
+
+
+def plan_items(num_windows, cfg, world):
+    """Work items of one denoising step, per rank: [[item, ...] for each rank]; an item is a tuple of the (window, half)
+    units ONE forward produces: ((w, 0), (w, 1)) = the whole window batched (b = 2), ((w, h),) = one CFG half (b = 1).
+
+    Whole windows are dealt first — a batched window costs 1.0, its two halves 1.30 — and only the last k windows are cut
+    into halves to level the ranks; k and the deal (longest item first onto the least loaded rank, ties to the lowest
+    rank) minimise the busiest rank's cost.  BASELINE configs[3] (10 windows, 8 ranks): 8 whole windows + 4 halves ->
+    four ranks carry 1.69 / 1.61, four carry 1.0: 10 / 1.69 = 5.9x (6.07x at the measured 54 ms per half) against 5.0x
+    for whole windows only and 5.2x for 20 half units.  Without CFG every window is one b = 1 item."""
+    if not cfg:
+        items = [((w, 0),) for w in range(num_windows)]
+        return _deal(items, world)
+    best = None
+    for k in range(num_windows + 1):
+        items = [((w, 0), (w, 1)) for w in range(num_windows - k)]
+        items += [((w, h),) for w in range(num_windows - k, num_windows) for h in (1, 0)]
+        ranks = _deal(items, world)
+        load = max(sum(_item_cost(i) for i in r) for r in ranks)
+        if best is None or load < best[0] - 1e-9:
+            best = (load, ranks)
+    return best[1]
+
+
+def _deal(items, world):
+    order = sorted(items, key=lambda i: (-_item_cost(i), i[0][0], -i[0][1]))
+    ranks, load = [[] for _ in range(world)], [0.0] * world
+    for it in order:
+        r = min(range(world), key=lambda q: (round(load[q], 9), q))
+        ranks[r].append(it)
+        load[r] += _item_cost(it)
+    return ranks
+
+
+def plan_load(num_windows, cfg, world):
+    """(per-rank cost in window-forward units, speed-up bound = num_windows (x 0.61 without CFG) / busiest rank)."""
+    ranks = plan_items(num_windows, cfg, world)
+    load = [sum(_item_cost(i) for i in r) for r in ranks]
+    one = num_windows * (ITEM_COST["window"] if cfg else ITEM_COST["uncond"])
+    return load, one / max(load) if max(load) > 0 else 1.0
+
+
+def assign_units(units, world, cfg=None):
+    """[(unit, rank, slot)] of plan_items: slot = the unit's index among its rank's units (item order; the two halves
+    of a whole window take consecutive slots, uncond first)."""
+    if cfg is None:
+        cfg = any(h == 1 for _, h in units)
+    nw = 1 + max(w for w, _ in units) if units else 0
+    out = []
+    for r, items in enumerate(plan_items(nw, cfg, world)):
+        slot = 0
+        for it in items:
+            for u in it:
+                out.append((u, r, slot))
+                slot += 1
+    return out
+
+
 def plan_units(num_windows, cfg, rank, world):
-    """Work decomposition of one denoising step.  Units = (window, half) in canonical order
-    (w0/uncond, w0/cond, w1/uncond, ...).  Assignment: cond halves (two KV segments: the heavier unit) first, then
-    uncond halves, dealt over the ranks in a snake (0..world-1, world-1..0, ...) so that every rank gets the same
-    number of units +-1 and heavy / light units alternate per rank.  Returns (all_units, my_units in slot order)."""
+    """Work decomposition of one denoising step.  Units = (window, half) in canonical order (w0/uncond, w0/cond,
+    w1/uncond, ...); returns (all_units, this rank's units in slot order).  See plan_items for the deal."""
     halves = (0, 1) if cfg else (0,)
     units = [(w, h) for w in range(num_windows) for h in halves]
-    return units, [u for u, r, _ in assign_units(units, world) if r == rank]
-
-
-def assign_units(units, world):
-    """[(unit, rank, slot)]: the snake deal of plan_units; slot = the unit's index among its rank's units."""
-    order = sorted(units, key=lambda u: (-u[1], u[0]))  # cond (half 1) first, window order inside
-    out, nslot = [], [0] * world
-    for k, u in enumerate(order):
-        rnd, pos = divmod(k, world)
-        r = pos if rnd % 2 == 0 else world - 1 - pos
-        out.append((u, r, nslot[r]))
-        nslot[r] += 1
-    return out
+    return units, [u for u, r, _ in assign_units(units, world, cfg) if r == rank]
 
 
 def _all_gather(send, world, group=None):
@@ -84,7 +140,7 @@ def sharded_frames(fn, x, rank, world, group=None):
 class UnitExchange:
     """Pre-allocated exchange of per-unit predictions (fp32 [Fw, h, w, C] each).
 
-    Rank r owns ceil/floor(len(units)/world) slots.  `put(slot, pred)` copies the prediction into the rank's send
+    Every rank owns as many slots as the busiest rank has units (assign_units).  `put(slot, pred)` copies the prediction into the rank's send
     slot and immediately starts the all-gather of THAT slot index over all ranks (async_op: RCCL runs it on its own
     stream, ordered after the producing kernels by an event), so the gather of slot k overlaps the compute of the
     rank's unit k+1.  `finish()` starts the gathers of slots this rank does not fill (it sends zeros there), waits
@@ -93,7 +149,7 @@ class UnitExchange:
     def __init__(self, units, rank, world, shape, device, group=None):
         self.units, self.rank, self.world, self.group = units, rank, world, group
         self.assign = assign_units(units, world)
-        self.nslots = math.ceil(len(units) / world) if units else 0
+        self.nslots = 1 + max((slot for _, _, slot in self.assign), default=-1)  # the busiest rank's unit count
         self.send = torch.zeros((self.nslots,) + tuple(shape), device=device, dtype=torch.float32)
         self.recv = torch.zeros((self.nslots, world) + tuple(shape), device=device, dtype=torch.float32)
         self.my_slots = sum(1 for _, r, _ in self.assign if r == rank)
@@ -218,6 +274,21 @@ class Pose2VideoPipeline:
         self.stage_times = None     # dict -> accumulates per-stage milliseconds (HIP events) of run_tensors
         self._graphs = {}
 
+    def _streams(self, dev):
+        """The side streams of `dev` for the CURRENT window_streams setting (a later change of the attribute takes effect;
+        each workspace slot these streams use pins one split-K scratch buffer in ops._WS, see ops.release_workspaces)."""
+        key = (torch.device(dev), int(self.window_streams))
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = [torch.cuda.Stream(dev) for _ in range(self.window_streams)]
+        return st
+
+    def prepack(self):
+        """Pack every model's weights on the CURRENT stream (see HipModule.prepack): must precede any stream fork."""
+        for m in (self.vae, self.pose_guider, self.reference_unet, self.denoising_unet):
+            if hasattr(m, "prepack"):
+                m.prepack(m.compute_dtype)
+
     def to(self, device=None, dtype=None):
         for m in (self.vae, self.image_encoder, self.reference_unet, self.denoising_unet, self.pose_guider):
             if isinstance(m, torch.nn.Module):
@@ -240,11 +311,14 @@ class Pose2VideoPipeline:
         -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
         dt = self.vae.compute_dtype
         outs = []
-        tokens_in = images.shape[-1] == 8 and images.dtype == dt
+        from .image import ImageTokens
+        tokens_in = isinstance(images, ImageTokens)
+        if tokens_in and images.dtype != dt:
+            raise ValueError(f"pre-tokenised images are {images.dtype}, the VAE computes in {dt}")
         nb = min(self.vae_batch, self.vae.max_images(*(images.shape[1:3] if tokens_in else images.shape[-2:])))
         for i in range(0, images.shape[0], nb):
             if tokens_in:
-                tok = images[i:i + nb].contiguous()
+                tok = images[i:i + nb].as_subclass(torch.Tensor).contiguous()
             else:
                 tok = ops.ncfhw_to_tokens(images[i:i + nb].float().contiguous()[:, :, None], dt, cpad=8)
             outs.append(self.vae.encode_tokens(tok))
@@ -288,6 +362,12 @@ class Pose2VideoPipeline:
         sched.set_timesteps(num_inference_steps)
         latents = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
         _, C, F, h, w = latents.shape
+        # lazily packed weights are packed HERE, on the main stream, before any side stream is forked: a side stream
+        # that hit a cache entry published by another stream would read buffers it is not ordered behind
+        self.prepack()
+        steps_t = sched.timesteps.tolist()
+        # sinusoidal embeddings of all timesteps of the clip: one small table built on the host and uploaded once
+        temb_tab = unet.timestep_table(steps_t, 2 if guidance_scale > 1.0 else 1)
 
         ehs_c = clip_embeds.to(dev).float().reshape(1, 1, -1)
         ehs = torch.cat([torch.zeros_like(ehs_c), ehs_c], 0) if cfg else ehs_c
@@ -305,8 +385,9 @@ class Pose2VideoPipeline:
         ref_lat = self._encode_frames(ref_image.to(dev))                       # [1,h,w,4]
 
         def pose_fn(frames):
-            if frames.shape[-1] == 8 and frames.dtype == self.pose_guider.compute_dtype:
-                tok = frames  # already half tokens (image.vae_preprocess)
+            from .image import ImageTokens
+            if isinstance(frames, ImageTokens):
+                tok = frames.as_subclass(torch.Tensor)  # already half tokens (image.vae_preprocess)
             else:
                 tok = ops.ncfhw_to_tokens(frames.float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
             return torch.cat([self.pose_guider.run_tokens(tok[i:i + self.vae_batch].contiguous())
@@ -323,7 +404,7 @@ class Pose2VideoPipeline:
         main = torch.cuda.current_stream(dev)
         side = None
         if world == 1 and self.window_streams > 1:
-            side = self._side_streams.setdefault(dev, [torch.cuda.Stream(dev) for _ in range(self.window_streams)])[0]
+            side = self._streams(dev)[0]
             side.wait_stream(main)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), ops.workspace_slot(1 if side is not None else 0):
             ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=self.reference_unet.compute_dtype)
@@ -353,9 +434,35 @@ class Pose2VideoPipeline:
         windows = get_context_scheduler(context_schedule)(0, num_inference_steps, F, context_frames, context_stride,
                                                           context_overlap)
         win_idx = [torch.tensor(c, dtype=torch.int32, device=dev) for c in windows]
-        win_bk = [bk_tok[c.long()] for c in win_idx]
         win_pose = [pose_tok[c.long()] for c in win_idx]
+        rep = (2 if cfg else 1) if world == 1 else 1
+        # Per-window UNet input [rep * Fw, h, w, 8] = (latent | background) channels, allocated once per clip: the
+        # background half is constant and written here for every CFG copy, the latent half is rewritten every step by
+        # the layout kernel (one launch per CFG copy) — no torch.cat / repeat inside the step loop.
+        win_x = []
+        for c in win_idx:
+            xw = torch.empty((rep * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+            xw[..., C:] = bk_tok[c.long()].repeat(rep, 1, 1, 1)
+            win_x.append(xw)
+        if rep > 1:
+            win_pose = [p_.repeat(rep, 1, 1, 1) for p_ in win_pose]
+
+        def fill_latents(wi):
+            idx, Fw = win_idx[wi], win_idx[wi].numel()
+            for r_ in range(rep):
+                ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=win_x[wi][r_ * Fw:(r_ + 1) * Fw])
+            return win_x[wi]
+
         units, my_units = plan_units(len(windows), cfg, rank, world)
+        my_items = plan_items(len(windows), cfg, world)[rank] if world > 1 else []
+        item_x, item_pose = [], []
+        for item in my_items:  # per-item UNet input / pose buffers of the sharded mode (same layout as win_x)
+            c = win_idx[item[0][0]]
+            xw = torch.empty((len(item) * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+            xw[..., C:] = bk_tok[c.long()].repeat(len(item), 1, 1, 1)
+            item_x.append(xw)
+            item_pose.append(pose_tok[c.long()].repeat(len(item), 1, 1, 1))
+        counter_x = torch.empty((F,), device=dev, dtype=torch.float32)  # the cond half's (unused) frame counter
         exch = None
         if world > 1:  # every window has the same frame count; the UNet's output head is padded to 4 channels
             cpad = (unet.out_channels + 3) // 4 * 4
@@ -363,7 +470,8 @@ class Pose2VideoPipeline:
         acc = torch.empty((2 if cfg else 1, C, F, h, w), device=dev, dtype=torch.float32)
         counter = torch.empty((F,), device=dev, dtype=torch.float32)
 
-        for step, t in enumerate(sched.timesteps.tolist()):
+        for step, t in enumerate(steps_t):
+            te = temb_tab[step]
             acc.zero_()
             counter.zero_()
             preds = {}
@@ -372,18 +480,14 @@ class Pose2VideoPipeline:
                 # CUs (tail rounds of small levels, HBM-bound linears beside MFMA-bound convolutions): -4.7 % per step at
                 # two windows (profiles/r2_two_stream_forward.txt).  Accumulation stays in canonical window order.
                 main = torch.cuda.current_stream(dev)
-                streams = self._side_streams.setdefault(dev, [torch.cuda.Stream(dev) for _ in range(self.window_streams)])
+                streams = self._streams(dev)
                 for s_ in streams:
                     s_.wait_stream(main)
-                rep = 2 if cfg else 1
                 wpred = []
                 for wi, idx in enumerate(win_idx):
                     slot = wi % len(streams)
                     with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot):
-                        lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
-                        x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
-                        wpred.append(unet.run_tokens(x.repeat(rep, 1, 1, 1), t, ehs, rep, idx.numel(),
-                                                     win_pose[wi].repeat(rep, 1, 1, 1)))
+                        wpred.append(unet.run_tokens(fill_latents(wi), t, ehs, rep, idx.numel(), win_pose[wi], t_emb=te))
                 for s_ in streams:
                     main.wait_stream(s_)
                 for pred, idx in zip(wpred, win_idx):
@@ -391,54 +495,61 @@ class Pose2VideoPipeline:
                     ops.window_accumulate(pred, idx, acc, counter)
             elif world == 1:
                 for wi, idx in enumerate(win_idx):
-                    lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)                   # [Fw,h,w,4]
-                    x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
-                    rep = 2 if cfg else 1
+                    x = fill_latents(wi)                                                         # [rep*Fw,h,w,8]
                     if self.use_graphs:
                         key = (rep, idx.numel(), h, w, dt)
                         if key not in self._graphs:
                             self._graphs[key] = GraphedDenoiser(unet, rep, idx.numel(), h, w, pose_tok.shape[-1], dt)
-                        pred = self._graphs[key](x.repeat(rep, 1, 1, 1), t, ehs, win_pose[wi].repeat(rep, 1, 1, 1))
+                        pred = self._graphs[key](x, t, ehs, win_pose[wi])
                     else:
-                        pred = unet.run_tokens(x.repeat(rep, 1, 1, 1), t, ehs, rep, idx.numel(),
-                                               win_pose[wi].repeat(rep, 1, 1, 1))
+                        pred = unet.run_tokens(x, t, ehs, rep, idx.numel(), win_pose[wi], t_emb=te)
                     ops.window_accumulate(pred, idx, acc, counter)
             else:
-                # a rank's units are independent b = 1 forwards: with two or more they run on alternating HIP streams
-                # (two half-batch forwards overlap 15 % better than back to back, profiles/r2_two_stream_forward.txt);
-                # each prediction is handed to the exchange, in unit order, as soon as its stream is done
-                conc = len(my_units) > 1 and self.window_streams > 1
+                # a rank's items (whole windows as b = 2 forwards, single halves as b = 1 forwards) are independent:
+                # with two or more they run on alternating HIP streams (profiles/r2_two_stream_forward.txt); each
+                # unit's prediction is handed to the exchange, in slot order, as soon as its stream is done
+                conc = len(my_items) > 1 and self.window_streams > 1
                 main = torch.cuda.current_stream(dev)
-                streams = self._side_streams.setdefault(dev, [torch.cuda.Stream(dev) for _ in range(self.window_streams)]) if conc else [main]
+                streams = self._streams(dev) if conc else [main]
                 if conc:
                     for s_ in streams:
                         s_.wait_stream(main)
                 pending = []
-                for k, (wi, half) in enumerate(my_units):
-                    idx = win_idx[wi]
-                    slot = k % len(streams)
-                    with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot if conc else 0):
-                        lat_tok = ops.ncfhw_to_tokens(latents, dt, frame_idx=idx)
-                        x = torch.cat([lat_tok, win_bk[wi]], dim=-1)
-                        e = ehs[half:half + 1] if cfg else ehs
-                        pred = self._run_unit(unet, x, t, e, idx.numel(), win_pose[wi], cond=(half == 1 or not cfg))
-                    pending.append((pred, streams[slot]))
-                    # the oldest pending unit is handed over once every stream has a younger unit queued behind it
-                    if len(pending) == len(streams):
-                        p0, s0 = pending.pop(0)
-                        if conc:
-                            main.wait_stream(s0)
-                            p0.record_stream(main)
-                        exch.put(p0)  # the gather of this unit's slot starts now and runs under the following units
-                for p0, s0 in pending:
+
+                def hand_over(entry):
+                    preds, s0 = entry
                     if conc:
                         main.wait_stream(s0)
-                        p0.record_stream(main)
-                    exch.put(p0)
+                    for p0 in preds:
+                        if conc:
+                            p0.record_stream(main)
+                        exch.put(p0)  # the gather of this unit's slot starts now and runs under the following items
+
+                for k, item in enumerate(my_items):
+                    wi = item[0][0]
+                    idx, Fw = win_idx[wi], win_idx[wi].numel()
+                    slot = k % len(streams)
+                    with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot if conc else 0):
+                        x = item_x[k]
+                        for r_ in range(len(item)):
+                            ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=x[r_ * Fw:(r_ + 1) * Fw])
+                        if len(item) == 2:  # the whole window, batched exactly as on one GPU
+                            pred = unet.run_tokens(x, t, ehs, 2, Fw, item_pose[k], t_emb=te)
+                            preds = [pred[:Fw], pred[Fw:]]
+                        else:
+                            half = item[0][1]
+                            e = ehs[half:half + 1] if cfg else ehs
+                            preds = [self._run_unit(unet, x, t, e, Fw, item_pose[k], cond=(half == 1 or not cfg), t_emb=te[:1])]
+                    pending.append((preds, streams[slot]))
+                    # the oldest pending item is handed over once every stream has a younger item queued behind it
+                    if len(pending) == len(streams):
+                        hand_over(pending.pop(0))
+                for entry in pending:
+                    hand_over(entry)
                 allp = exch.finish()
-                for wi, idx in enumerate(win_idx):
-                    halves = [allp[(wi, hf)] for hf in ((0, 1) if cfg else (0,))]
-                    ops.window_accumulate(torch.cat(halves, 0).contiguous(), idx, acc, counter)
+                for wi, idx in enumerate(win_idx):  # canonical window order, uncond then cond: the single-GPU sums
+                    for hf in ((0, 1) if cfg else (0,)):
+                        ops.window_accumulate(allp[(wi, hf)], idx, acc[hf:hf + 1], counter if hf == 0 else counter_x)
             ops.cfg_ddim_step(acc, counter, latents, cfg, guidance_scale, *sched.coefficients(t))
             if trajectory is not None:
                 trajectory.append(latents.clone())
@@ -462,7 +573,7 @@ class Pose2VideoPipeline:
                 self.stage_times[n1] = self.stage_times.get(n1, 0.0) + e0.elapsed_time(e1)
         return (video, latents) if return_latents else video
 
-    def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond):
+    def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond, t_emb=None):
         """One (window, CFG half) unit as a b = 1 forward.  The uncond half must not read the bank."""
         blocks = unet.spatial_blocks()
         saved = None
@@ -471,7 +582,7 @@ class Pose2VideoPipeline:
             for b in blocks:
                 b.bank_kv = None
         try:
-            return unet.run_tokens(x, t, ehs1, 1, Fw, pose)
+            return unet.run_tokens(x, t, ehs1, 1, Fw, pose, t_emb=t_emb)
         finally:
             if saved is not None:
                 for b, kv in zip(blocks, saved):

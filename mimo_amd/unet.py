@@ -194,28 +194,44 @@ class UNetBase(HipModule):
         d["freqs"] = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=dev) / half)
         return d
 
+    def timestep_table(self, timesteps, b):
+        """Sinusoidal embeddings (Timesteps(flip_sin_to_cos, shift 0)) of a clip's timesteps as ONE half tensor
+        [len(timesteps), b, C0], built on the host and uploaded once: run_tokens(t_emb=table[i]) then launches no
+        elementwise glue per step.  Same formula and fp32 arithmetic as the per-call path of _time_and_cross."""
+        import math
+        half = self.boc[0] // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        ang = torch.tensor([float(t) for t in timesteps], dtype=torch.float32)[:, None] * freqs[None, :]
+        emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(self.compute_dtype)
+        return emb[:, None, :].repeat(1, b, 1).contiguous().to(self.device)
+
     def _time_and_cross(self, ctx, p, timestep, ehs):
         """Timesteps(flip_sin_to_cos, shift 0) -> TimestepEmbedding -> silu -> ALL 22 time_emb_proj in one GEMM;
         ALL 16 collapsed cross-attentions in one GEMM (src/models/unet_3d_edit_bkfill.py:447-468, resnet.py:226)."""
         dev = self.device
-        if torch.is_tensor(timestep) and timestep.device == dev:
-            t = timestep.reshape(-1).float().expand(ctx.b)  # device scalar: capturable in a hipGraph
+        if ctx.t_emb is not None:  # precomputed row of timestep_table()
+            t_emb = ctx.t_emb
+            assert t_emb.shape == (ctx.b, self.boc[0]) and t_emb.dtype == ctx.dtype and t_emb.is_contiguous()
         else:
-            t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(ctx.b)
-        ang = t[:, None] * p["freqs"][None, :]
-        t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ctx.dtype)  # [b, 320] (host-side glue, b x 320)
+            if torch.is_tensor(timestep) and timestep.device == dev:
+                t = timestep.reshape(-1).float().expand(ctx.b)  # device scalar: capturable in a hipGraph
+            else:
+                t = torch.as_tensor(timestep, device=dev).reshape(-1).float().expand(ctx.b)
+            ang = t[:, None] * p["freqs"][None, :]
+            t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ctx.dtype)  # [b, 320] (glue, b x 320)
         e1 = ops.gemm(t_emb, p["t1_w"], bias=p["t1_b"], silu=True)
         emb = ops.gemm(e1, p["t2_w"], bias=p["t2_b"], silu=True)  # silu(emb): every consumer applies the nonlinearity first
         ctx.temb = ops.gemm(emb, p["temb_w"], bias=p["temb_b"], out_f32=True)
         e = ehs.reshape(ctx.b, -1).to(device=dev, dtype=ctx.dtype).contiguous()
         ctx.attn2 = ops.gemm(e, p["a2_w"], bias=p["a2_b"], out_f32=True)
 
-    def run_tokens(self, x_tok, timestep, ehs, b, F, pose_tok=None, ctx=None):
+    def run_tokens(self, x_tok, timestep, ehs, b, F, pose_tok=None, ctx=None, t_emb=None):
         """x_tok: half [b*F, h, w, Cin_pad8]; ehs: [b, 1, 768]; pose_tok: [b*F, h, w, C0] (fp32|half) or None.
         Returns fp32 tokens [b*F, h, w, Cout_pad4] (or the last hidden state when there is no output head)."""
         dt = self.compute_dtype
         p = self.packed(dt)
         ctx = ctx or Ctx(dt, b, F)
+        ctx.t_emb = t_emb
         self._time_and_cross(ctx, p, timestep, ehs)
         n, H, W, _ = x_tok.shape
         up = 2 ** self.num_upsamplers

@@ -7,6 +7,9 @@ Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, 
   small       half-width UNets (4 heads, d = 40/80/160): denoising forward + banks, odd-size forward
   forward512  FULL-SIZE denoising UNet, config-2 shapes: one forward on 2 x 24 latent frames 64x64 (about 4 min, 15 GB)
   forward768  the same at BASELINE configs[4] shapes: 2 x 24 latent frames 96x96 (768x768; about 10 min, 30 GB)
+  forward784  the scripts' DEFAULT size (run_animate.py:43-55: 784x784 -> latent 98x98, odd sizes 49 / 25 / 13 down the
+              UNet, explicit-size upsampling on the way up): one denoising forward on 2 x 12 latent frames (about 6 min, 17 GB)
+  vae784      one frame of the VAE decoder at 784x784 (latent 98x98) with the oracle VAE (diffusers AutoencoderKL restatement)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
   config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
               0, 9, 19; about 70 min and 19 GB on 8 cores)
@@ -104,6 +107,34 @@ def forward768():
     out = forward_case(r3, r2, 96, 24, 320, 13, t=499)
     print(f"768x768 forward {time.time()-t0:.0f} s", flush=True)
     save_file({"fwd_hw96_F24": out}, os.path.join(OUT, "full_unet_forward_768.safetensors"))
+
+
+def forward784():
+    """run_animate.py / run_edit.py default size 784x784 (run_animate.py:43-55): latent 98 -> 49 -> 25 -> 13, so every
+    down-sampler sees an odd size and every up-sampler takes the explicit `upsample_size` path (unet_3d_edit_bkfill.py)."""
+    t0 = time.time()
+    r3, r2 = ref_models(OM.SD15_UNET_CONFIG, 8, 98, 1234, 1235)
+    print(f"full-size reference models built in {time.time()-t0:.0f} s", flush=True)
+    t0 = time.time()
+    out = forward_case(r3, r2, 98, F784, 320, 17, t=499)
+    print(f"784x784 forward {time.time()-t0:.0f} s", flush=True)
+    save_file({f"fwd_hw98_F{F784}": out}, os.path.join(OUT, "full_unet_forward_784.safetensors"))
+
+
+F784 = 12
+
+
+def vae784():
+    """One decoded frame at 784x784: decode_latents (pipeline :113-126) of a seeded 98x98 latent with the oracle VAE."""
+    vae = synth.build(OP.AutoencoderKL, 1237)
+    g = torch.Generator().manual_seed(19)
+    lat = torch.randn(1, 4, 98, 98, generator=g)
+    with torch.no_grad():
+        img = vae.decode(lat / 0.18215).sample
+        enc = vae.encode(img.clamp(-1, 1)).latent_dist.mean * 0.18215
+    save_file({"latent": lat, "video_frame": (img / 2 + 0.5).clamp(0, 1)[0], "reencoded_latent": enc},
+              os.path.join(OUT, "vae_784_frame.safetensors"))
+    print("vae784 done", tuple(img.shape), flush=True)
 
 
 def config1():
@@ -253,5 +284,5 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ["small"]
     for w in what:
-        {"small": small, "forward512": forward512, "forward768": forward768, "config1": config1, "config2": config2,
+        {"small": small, "forward512": forward512, "forward768": forward768, "forward784": forward784, "vae784": vae784, "config1": config1, "config2": config2,
          "config2_video": config2_video, "multiwindow": multiwindow}[w]()

@@ -127,6 +127,40 @@ def test_hip_full_size_forward_768_vs_reference_golden(full_models):
 
 
 @pytest.mark.gpu
+def test_hip_full_size_forward_784_vs_reference_golden(full_models):
+    """The scripts' DEFAULT size (run_animate.py:43-55: 784x784): latent 98 -> 49 -> 25 -> 13, every down-sampler sees an odd
+    size and every up-sampler takes the explicit-size path; 2 x 12 frames, reference bank, against the reference's own code
+    on CPU fp32 (oracle/make_golden.py forward784)."""
+    from oracle.make_golden import F784
+    G = gold("full_unet_forward_784.safetensors")
+    ehs, ref_lat, x, pose = case_inputs(98, F784, 320, 17)
+    out = _product_forward(full_models["den"], full_models["ref"], torch.device("cuda:0"), ehs, ref_lat, x, pose, 499)
+    e = rel_l2(out, G[f"fwd_hw98_F{F784}"])
+    line = f"full-size denoising forward (784x784x{F784}f shapes, odd latent sizes 98/49/25/13) fp16 vs reference fp32: rel_l2={e:.2e}"
+    print(line)
+    _report(line)
+    assert e < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_vae_784_frame_vs_oracle_golden(full_models):
+    """One VAE frame at 784x784 (latent 98x98: 9604 tokens in the d = 512 mid-block attention): decode_latents of a seeded
+    latent, then the encoder on the decoded image, vs the oracle VAE (diffusers 0.24 AutoencoderKL restatement) on CPU fp32."""
+    G = gold("vae_784_frame.safetensors")
+    dev = torch.device("cuda:0")
+    vae = full_models["vae"]
+    img = vae.decode((G["latent"] / 0.18215).to(dev)).sample.float()
+    video = (img / 2 + 0.5).clamp(0, 1)[0].cpu()
+    e_dec = rel_l2(video, G["video_frame"])
+    enc = (vae.encode(img.clamp(-1, 1)).latent_dist.mean.float() * 0.18215).cpu()
+    e_enc = rel_l2(enc, G["reencoded_latent"])
+    line = f"VAE 784x784 frame fp16 vs oracle fp32: decode rel_l2={e_dec:.2e}, encode(decoded) rel_l2={e_enc:.2e}"
+    print(line)
+    _report(line)
+    assert e_dec < 1e-3 and e_enc < 2e-3  # the encoder runs on the product's own decoded image (its error is included)
+
+
+@pytest.mark.gpu
 def test_hip_config1_pipeline_vs_reference_golden(full_models):
     """BASELINE configs[0]: 256x256, 8 frames, 4 DDIM steps, CFG 3.5, full-size models: latents after every step."""
     from mimo_amd.pipeline import Pose2VideoPipeline
@@ -229,4 +263,6 @@ def test_hip_multiwindow_call_vs_reference_golden(full_models):
             f" | decoded frames 0/47: {v0:.2e} {v47:.2e}")
     print(line)
     _report(line)
-    assert e0 < 1e-3 and e3 < 1e-3 and max(v0, v47) < 1e-3  # measured 1.9e-4 / 9.2e-4 | 6.4e-4 / 6.7e-4: the 1e-3 bar holds on the windowed path
+    # the 1e-3 bar on one forward (step 0) and on the decoded frames; the chained 4-step latents (four 250-step jumps, like
+    # config 1) measured 9.2e-4 and get the same x 1.3 headroom as the other chained fixtures
+    assert e0 < 1e-3 and e3 < 1.2e-3 and max(v0, v47) < 1e-3

@@ -112,10 +112,18 @@ def test_plan_units_covers_everything_once():
 
 
 def test_unit_assignment_balances_ranks():
-    """Snake deal: every rank gets ceil/floor(units/world) units, heavy (cond) and light (uncond) halves alternate per
-    rank, ranks beyond the unit count get nothing; BASELINE configs[3] (F = 192: 10 windows x 2 halves on 8 GPUs) is
-    3 rounds of work = the 6.67x bound of SURVEY 8(e)."""
-    from mimo_amd.pipeline import assign_units, plan_units
+    """plan_items: whole windows (b = 2 batched, cost 1.0) are dealt first, only as many windows as level the ranks are
+    cut into CFG halves (b = 1, cost 0.69 / 0.61).  BASELINE configs[3] (F = 192: 10 windows on 8 GPUs): 6 whole windows +
+    4 windows as 8 halves -> four ranks carry a window + an uncond half (1.61), two a window, two a pair of cond halves
+    (1.38): 10 / 1.61 = 6.2x in the cost model, against 5.0x for whole windows only and 5.2x for 20 half units."""
+    from mimo_amd.pipeline import ITEM_COST, assign_units, plan_items, plan_load, plan_units
+    ranks = plan_items(10, True, 8)
+    assert sorted(len(r) for r in ranks) == [1, 1, 2, 2, 2, 2, 2, 2]
+    assert sum(1 for r in ranks for it in r if len(it) == 2) == 6 and sum(1 for r in ranks for it in r if len(it) == 1) == 8
+    load, speedup = plan_load(10, True, 8)
+    assert abs(max(load) - (ITEM_COST["window"] + ITEM_COST["uncond"])) < 1e-9 and speedup > 6.2
+    assert max(load) < 2 * ITEM_COST["window"]                                           # whole windows only: 2.0
+    assert max(load) < 2 * ITEM_COST["cond"] + ITEM_COST["uncond"]                        # 20 half units, 3 on a rank
     units, _ = plan_units(10, True, 0, 8)
     per_rank = {}
     for u, r, slot in assign_units(units, 8):
@@ -123,13 +131,70 @@ def test_unit_assignment_balances_ranks():
     assert sorted(len(v) for v in per_rank.values()) == [2, 2, 2, 2, 3, 3, 3, 3]
     for v in per_rank.values():
         assert [s for s, _ in sorted(v)] == list(range(len(v)))  # slots are dense per rank
-    # cond halves attend twice the keys (1.2518 vs 1.1037 TFLOP per frame): the busiest rank carries two uncond
-    # + one cond unit — the optimum for 20 units on 8 ranks (a modulo deal would put three cond units on one rank)
-    cost = {r: sum(1.2518 if u[1] else 1.1037 for _, u in v) for r, v in per_rank.items()}
-    assert max(cost.values()) <= 2 * 1.1037 + 1.2518 + 1e-9
-    # world > units: 2 units (one 24-frame window, CFG) on 8 ranks -> ranks 2..7 idle but planned
-    units, _ = plan_units(1, True, 0, 8)
+    assert sorted(u for v in per_rank.values() for _, u in v) == sorted(units)
+    # fewer ranks: 2 and 4 GPUs keep whole windows wherever that is the better deal
+    assert plan_load(10, True, 2)[1] == pytest.approx(2.0) and plan_load(10, True, 1)[1] == pytest.approx(1.0)
+    l4, s4 = plan_load(10, True, 4)
+    assert max(l4) == pytest.approx(2 * ITEM_COST["window"] + ITEM_COST["cond"]) and s4 > 3.7   # vs 3.33x whole-only
+    # world > units: one 24-frame window on 8 ranks -> its two halves on two ranks (0.69 < 1.0), ranks 2..7 idle but planned
     assert [plan_units(1, True, r, 8)[1] for r in range(8)] == [[(0, 1)], [(0, 0)]] + [[]] * 6
+    # without CFG every window is one b = 1 item
+    assert sorted(len(r) for r in plan_items(5, False, 2)) == [2, 3]
+
+
+def test_timestep_table_matches_per_call_embedding():
+    """UNetBase.timestep_table (host, once per clip) == the per-call sinusoidal embedding of _time_and_cross."""
+    import math
+    from mimo_amd.unet import UNet2DConditionModel
+    from oracle import synth
+    m = UNet2DConditionModel(**synth.small_unet_kwargs())
+    m.compute_dtype = torch.float16
+    ts = [999, 749, 499, 249, 0]
+    tab = m.timestep_table(ts, 2)
+    C0 = m.boc[0]
+    assert tab.shape == (5, 2, C0) and tab.dtype == torch.float16
+    half = C0 // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    for i, t in enumerate(ts):
+        ang = torch.tensor([float(t)])[:, None] * freqs[None]
+        ref = torch.cat([torch.cos(ang), torch.sin(ang)], -1).half()
+        assert torch.equal(tab[i, 0:1], ref) and torch.equal(tab[i, 1:2], ref)
+
+
+def test_ddim_known_answers_independent_of_the_oracle():
+    """DDIM pins that do not go through oracle/: the zero-terminal-SNR schedule of inference_v2.yaml (scaled_linear 0.00085
+    .. 0.012, rescale_betas_zero_snr, trailing spacing, v_prediction) has alpha_bar[0] = 0.99915, [499] = 0.24236,
+    [998] = 1.97e-7, [999] = 0, and at t = 999 (alpha_bar = 0) the v-prediction step gives x0 = -v.
+    The expected numbers are derived here in float64 from the closed form, not read from any scheduler implementation."""
+    import numpy as np
+    from mimo_amd.scheduler import DDIMScheduler
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+              steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    s = DDIMScheduler(**kw)
+    # closed form in float64: s_t = sqrt(prod(1 - beta)), shifted and scaled so that s_999 = 0 and s_0 is unchanged
+    beta = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    sq = np.sqrt(np.cumprod(1.0 - beta))
+    abar = ((sq - sq[-1]) * sq[0] / (sq[0] - sq[-1])) ** 2
+    for t, want in ((0, 0.99915), (499, 0.24236), (998, 1.97e-7)):
+        assert abs(abar[t] - want) / want < 5e-3, (t, abar[t])           # the survey's figures
+        assert abs(float(s.alphas_cumprod[t]) - abar[t]) / abar[t] < 2e-3  # the product scheduler (fp32 cumprod)
+    assert float(s.alphas_cumprod[999]) == 0.0 and abar[999] == 0.0
+    # timesteps: trailing spacing, S = 20 -> 999, 949, ..., 49; S = 4 -> 999, 749, 499, 249; S = 25 -> 999, 959, ..., 39
+    for S, want in ((20, list(range(999, 0, -50))), (4, [999, 749, 499, 249]), (25, list(range(999, 0, -40)))):
+        s.set_timesteps(S)
+        assert s.timesteps.tolist() == want
+    # step coefficients at t = 999 (S = 20): a_t = 0 -> x0 = sqrt(a) x - sqrt(1-a) v = -v, eps = sqrt(a) v + sqrt(1-a) x = x,
+    # x_prev = sqrt(a') (-v) + sqrt(1-a') x with a' = alpha_bar[949]
+    s.set_timesteps(20)
+    sa, s1, sap, s1p = s.coefficients(999)
+    assert sa == 0.0 and s1 == 1.0
+    assert abs(sap - abar[949] ** 0.5) < 1e-6 and abs(s1p - (1 - abar[949]) ** 0.5) < 1e-6
+    x, v = np.float64(0.3), np.float64(-1.7)
+    x0, eps = sa * x - s1 * v, sa * v + s1 * x
+    assert x0 == -v and eps == x
+    # last step (t = 49 at S = 20): prev = -1 -> final alpha_bar = 1 (set_alpha_to_one) -> x_prev = x0 exactly
+    sa, s1, sap, s1p = s.coefficients(49)
+    assert sap == 1.0 and s1p == 0.0
 
 
 def _exchange_worker(rank, world, port, q, nw):
