@@ -775,6 +775,205 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// attn512_kernel: ONE head of d = 512 — the mid-block attention of the VAE (diffusers UNetMidBlock2D, 1-head
+// Attention(residual_connection) over the H*W tokens of a latent image: 4096 tokens at 512x512, 9216 at 768x768,
+// 9604 at 784x784).  Flash form: the N x N score matrix (340 MB per image at 768x768 in the GEMM + softmax + GEMM
+// form this replaces) never exists.  A lane cannot own a 512-wide output row (256 accumulator registers), so the head
+// dimension is split over the 4 waves of a block: wave w owns channels [128 w, 128 w + 128) of Q, K, V and O for the
+// block's 32 queries.  Per 64-key tile every wave
+//   1. computes the PARTIAL S^T = K[:, slice].Q[:, slice]^T of its slice (K fragments straight from global memory: a
+//      fragment is 16 contiguous bytes per lane, all query blocks of an image re-read the same K from L2),
+//   2. exchanges it through LDS: the four partials are summed in one fixed order by every wave (all waves hold the
+//      SAME full scores, hence the same running max / sum: no second exchange),
+//   3. runs the online softmax redundantly and multiplies P^T into its own 128 x 32 slice of O^T, V^T fragments coming
+//      out of a wave-private row-major V patch by ds_read_b64_tr_b16 (as in temporal_attn2_kernel).
+// ------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256, 1) void attn512_kernel(const AttnArgs a) {
+  constexpr int D = 512, DW = 128, KS = DW / 16, OT = DW / 32;
+  constexpr int VPB = DW * 2;                // V patch row pitch in bytes
+  constexpr int VB = KV_TILE * VPB;          // 16 KB per wave
+  constexpr int SB = 8 * 64 * 16;            // one wave's partial S^T: 8 x f32x4 per lane = 8 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * VB + 4 * SB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h2 = lane >> 5, li = lane & 31, g = lane >> 4, i16 = lane & 15;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 32;
+  const int dw0 = wave * DW;
+  unsigned char* const vpatch = smem + wave * VB;
+  f32x4* const sred = reinterpret_cast<f32x4*>(smem + 4 * VB);
+
+  const uint16_t* qb = a.q + (int64_t)b * a.Nq * a.ldq;
+  const uint16_t* kb = a.k + (int64_t)b * a.Nk * a.ldk;
+  const uint16_t* vb = a.v + (int64_t)b * a.Nk * a.ldv;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)((int64_t)a.Nq * a.ldq * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)((int64_t)a.Nk * a.ldk * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)((int64_t)a.Nk * a.ldv * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // Q^T fragments of this wave's channel slice (B operand): lane (h2, q = li) holds Q[q][dw0 + 16 s + 8 h2 .. + 8]
+  uint4 qf[KS];
+  {
+    const int qr = q0 + li;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+          rq, qr < a.Nq ? (unsigned)(((int64_t)qr * a.ldq + dw0 + 16 * s + 8 * h2) * 2) : OOB, 0, 0);
+      qf[s] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  }
+  f32x16 ot[OT];
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = a.scale_log2;
+  const int T = (a.Nk + KV_TILE - 1) / KV_TILE;
+  const unsigned ldkb = (unsigned)(a.ldk * 2), ldvb = (unsigned)(a.ldv * 2);
+  const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)vpatch +
+                         (unsigned)((4 * h2 + (i16 >> 2)) * VPB + (16 * (g & 1) + 4 * (i16 & 3)) * 2);
+
+  for (int t = 0; t < T; ++t) {
+    const int kv0 = t * KV_TILE;
+    // ---- global loads of the tile: K fragments (A operand: lane (h2, kv = li)) and V chunks (row 4 j + (lane >> 4),
+    // 16-byte chunk lane & 15 of the 128-channel slice); rows past the end read zeros ----
+    uint4 kf[2][KS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kr = kv0 + 32 * u + li;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+            rk, kr < a.Nk ? (unsigned)kr * ldkb + (unsigned)((dw0 + 16 * s + 8 * h2) * 2) : OOB, 0, 0);
+        kf[u][s] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
+    u32x4 vreg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int vr = kv0 + 4 * j + (lane >> 4);
+      vreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rv, vr < a.Nk ? (unsigned)vr * ldvb + (unsigned)((dw0 + 8 * (lane & 15)) * 2) : OOB, 0, 0);
+    }
+    // ---- partial S^T over this wave's 128 channels ----
+    f32x16 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) st[u] = HT<DT>::mfma32(kf[u][s], qf[s], st[u]);
+    }
+    // ---- exchange: every wave sums the four partials in the order 0, 1, 2, 3 ----
+    if (t > 0) __syncthreads();  // the previous tile's partials have been read by every wave
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        sred[(wave * 8 + u * 4 + i) * 64 + lane] = (f32x4){st[u][4 * i], st[u][4 * i + 1], st[u][4 * i + 2], st[u][4 * i + 3]};
+    // (the V rows are parked in the wave-private patch while the partials travel; the previous tile's transposed reads
+    // were waited for, and DS operations of a wave execute in order)
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint4*>(vpatch + (4 * j + (lane >> 4)) * VPB + (lane & 15) * 16) = make_uint4(vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 sum = sred[(0 * 8 + u * 4 + i) * 64 + lane];
+        sum += sred[(1 * 8 + u * 4 + i) * 64 + lane];
+        sum += sred[(2 * 8 + u * 4 + i) * 64 + lane];
+        sum += sred[(3 * 8 + u * 4 + i) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[u][4 * i + r] = sum[r];
+      }
+    // ---- online softmax (raw-score running max, scale folded into the exp2 argument), as attn_kernel ----
+    if (kv0 + KV_TILE > a.Nk) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (kv >= a.Nk) st[u][r] = -INFINITY;
+        }
+    }
+    float mt = st[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[u][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+      const float alpha = fast_exp2((m_run - m_use) * c);  // m_run = -inf -> 0
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < OT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    const float mc = -m_use * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(fmaf(st[u][r], c, mc));
+        st[u][r] = pv;
+        ps += pv;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run += ps;
+    uint4 pf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = u >> 1, hh = u & 1;
+      pf[u].x = pack2<DT>(st[tt][8 * hh + 0], st[tt][8 * hh + 1]);
+      pf[u].y = pack2<DT>(st[tt][8 * hh + 2], st[tt][8 * hh + 3]);
+      pf[u].z = pack2<DT>(st[tt][8 * hh + 4], st[tt][8 * hh + 5]);
+      pf[u].w = pack2<DT>(st[tt][8 * hh + 6], st[tt][8 * hh + 7]);
+    }
+    // ---- O^T[slice] += V^T.P^T: k-slot j of fragment u is key 16 u + 4 h2 + {0,1,2,3,8,9,10,11}[j] ----
+#pragma unroll
+    for (int dt = 0; dt < OT; ++dt) {
+      uint2 tl[4], th[4];
+      const unsigned va = vbase + (unsigned)(32 * dt * 2);
+#define MIMO_TR512(dst, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "i"(off) : "memory")
+      MIMO_TR512(tl[0], 0 * VPB);  MIMO_TR512(th[0], 8 * VPB);
+      MIMO_TR512(tl[1], 16 * VPB); MIMO_TR512(th[1], 24 * VPB);
+      MIMO_TR512(tl[2], 32 * VPB); MIMO_TR512(th[2], 40 * VPB);
+      MIMO_TR512(tl[3], 48 * VPB); MIMO_TR512(th[3], 56 * VPB);
+#undef MIMO_TR512
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(th[0]), "+v"(th[1]), "+v"(th[2]), "+v"(th[3])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ot[dt] = HT<DT>::mfma32(make_uint4(tl[u].x, tl[u].y, th[u].x, th[u].y), pf[u], ot[dt]);
+    }
+  }
+  // ---- epilogue: lane (h2, q) holds O^T[d = dw0 + 32 dt + (r & 3) + 8 (r >> 2) + 4 h2][q] ----
+  const int qr = q0 + li;
+  if (qr < a.Nq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    uint16_t* op = a.out + ((int64_t)b * a.Nq + qr) * a.ldo + dw0;
+#pragma unroll
+    for (int dt = 0; dt < OT; ++dt)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int d = 32 * dt + 8 * cc + 4 * h2;
+        uint2 o;
+        o.x = pack2<DT>(ot[dt][4 * cc + 0] * inv, ot[dt][4 * cc + 1] * inv);
+        o.y = pack2<DT>(ot[dt][4 * cc + 2] * inv, ot[dt][4 * cc + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Temporal attention: one wave per (batch b, pixel p, head h); sequence = F <= 32 frames.
 // ------------------------------------------------------------------------------------
 struct TAttnArgs {
@@ -893,6 +1092,158 @@ __global__ __launch_bounds__(256, 2) void temporal_attn_kernel(const TAttnArgs a
 }
 
 // ------------------------------------------------------------------------------------
+// Temporal attention, second form (the one mimo_temporal_attention launches when the row strides allow 16-byte
+// accesses): same wave <-> (batch, pixel, head) mapping and the same Q.K^T / softmax arithmetic as temporal_attn_kernel,
+// but every global access is a 16-byte lane access.  The first form gathered V^T with 2-byte loads (32 load instructions
+// per lane at d = 40, each lane its own request) and stored O^T as 8-byte pieces: rocprofv3 showed its waves 79 % of
+// the time issue-stalled at twice its byte roofline.  Here V rows are fetched as whole 16-byte chunks (2 instructions per
+// lane at d = 40), parked row-major in a wave-private LDS patch and read back TRANSPOSED by ds_read_b64_tr_b16 (the
+// hardware hands lane i column i of a [4 frames][16 channels] block: exactly the V^T fragment of the 32x32x16 MFMA);
+// O goes through a second patch and leaves as 16-byte stores of whole (frame, head) rows.
+// The patches are wave-private: DS operations of one wave execute in order, no barrier is needed.
+// ------------------------------------------------------------------------------------
+template <int DT, int D>
+__global__ __launch_bounds__(256, 2) void temporal_attn2_kernel(const TAttnArgs a) {
+  constexpr int KS = (D + 15) / 16;
+  constexpr int OT = (D + 31) / 32;
+  constexpr int DC = D / 8;                 // 16-byte chunks per (frame, head) row
+  constexpr int VP = 32 * OT;               // V patch row pitch (halfs): the padded channel count
+  constexpr int VB = 32 * VP * 2;           // bytes: 32 frame rows (rows >= F stay zero)
+  constexpr int OB = 32 * D * 2;            // bytes: O patch, dense [frame][D]
+  constexpr int NV = (32 * DC + 63) / 64;   // 16-byte chunks per lane that cover 32 rows
+  static_assert(D % 8 == 0, "rows are whole 16-byte chunks");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * (VB + OB)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h2 = lane >> 5, li = lane & 31, g = lane >> 4, i16 = lane & 15;
+  unsigned char* const vpatch = smem + wave * (VB + OB);
+  unsigned char* const opatch = vpatch + VB;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nunits = (int64_t)a.b * a.HW * a.heads;
+  if (unit >= nunits) return;
+  const int head = (int)(unit % a.heads);
+  const int64_t bp = unit / a.heads;
+  const int64_t pix = bp % a.HW;
+  const int bi = (int)(bp / a.HW);
+  const int F = a.F;
+  const int64_t row0 = (int64_t)bi * F * a.HW + pix;  // token row of frame f: row0 + f * HW
+
+  const int64_t tot_rows = (int64_t)a.b * F * a.HW;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (int)(tot_rows * a.ldq * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.k, 0, (int)(tot_rows * a.ldk * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.v, 0, (int)(tot_rows * a.ldv * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- every global load of the unit is issued up front: V chunks first (they take the longest way) ----
+  u32x4 vreg[NV];
+  int vrow[NV], vcc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = lane + 64 * j;
+    vrow[j] = c / DC;
+    vcc[j] = c - vrow[j] * DC;
+    const bool ok = vrow[j] < F;
+    vreg[j] = __builtin_amdgcn_raw_buffer_load_b128(
+        rv, ok ? (unsigned)(((row0 + (int64_t)vrow[j] * a.HW) * a.ldv + head * D + vcc[j] * 8) * 2) : OOB, 0, 0);
+  }
+  u32x4 kv4[KS], qv4[KS];
+  {
+    const bool fok = li < F;
+    const int64_t row = row0 + (int64_t)li * a.HW;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int kk = 16 * s + 8 * h2;
+      const bool ok = fok & (kk < D);
+      kv4[s] = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (unsigned)((row * a.ldk + head * D + kk) * 2) : OOB, 0, 0);
+      qv4[s] = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (unsigned)((row * a.ldq + head * D + kk) * 2) : OOB, 0, 0);
+    }
+  }
+  // zero the V patch (rows >= F and channels >= D are never written: they must read as zeros, p = 0 times garbage
+  // could be NaN), then park the V rows
+  for (int i = lane; i < VB / 16; i += 64) reinterpret_cast<uint4*>(vpatch)[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (vrow[j] < F)
+      *reinterpret_cast<uint4*>(vpatch + (vrow[j] * VP + vcc[j] * 8) * 2) = make_uint4(vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w);
+
+  // ---- S^T = K.Q^T (32 frames x 32 frames), softmax over the key frames: identical to temporal_attn_kernel ----
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    st = HT<DT>::mfma32(make_uint4(kv4[s].x, kv4[s].y, kv4[s].z, kv4[s].w), make_uint4(qv4[s].x, qv4[s].y, qv4[s].z, qv4[s].w), st);
+  float mt = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kv = (r & 3) + 8 * (r >> 2) + 4 * h2;
+    const float sv = kv < F ? st[r] * a.scale_log2 : -INFINITY;
+    st[r] = sv;
+    mt = fmaxf(mt, sv);
+  }
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float p = fast_exp2(st[r] - mt);
+    st[r] = p;
+    ps += p;
+  }
+  ps += __shfl_xor(ps, 32, 64);
+  const float inv = 1.f / ps;
+  uint4 pf[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    pf[u].x = pack2<DT>(st[8 * u + 0], st[8 * u + 1]);
+    pf[u].y = pack2<DT>(st[8 * u + 2], st[8 * u + 3]);
+    pf[u].z = pack2<DT>(st[8 * u + 4], st[8 * u + 5]);
+    pf[u].w = pack2<DT>(st[8 * u + 6], st[8 * u + 7]);
+  }
+  // ---- O^T += V^T.P^T.  k-slot j of fragment u is frame 16 u + 4 h2 + {0,1,2,3,8,9,10,11}[j] (the accumulator layout of
+  // S^T).  Transposed read: inside a 16-lane group lane m supplies the address of 4 consecutive channels of frame row
+  // (m >> 2), channel chunk (m & 3); lane i receives channel i of those 4 rows.  Group g covers channels 16 (g & 1) ..
+  // of the 32-channel tile and frames 4 (g >> 1) .. ----
+  const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)vpatch +
+                         (unsigned)(((4 * h2 + (i16 >> 2)) * VP + 16 * (g & 1) + 4 * (i16 & 3)) * 2);
+#pragma unroll
+  for (int dt = 0; dt < OT; ++dt) {
+    uint2 t00, t01, t10, t11;
+    const unsigned va = vbase + (unsigned)(32 * dt * 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t00) : "v"(va) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t01) : "v"(va), "i"(8 * VP * 2) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t10) : "v"(va), "i"(16 * VP * 2) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t11) : "v"(va), "i"(24 * VP * 2) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t00), "+v"(t01), "+v"(t10), "+v"(t11)::"memory");
+    __builtin_amdgcn_sched_barrier(0);  // no MFMA may be hoisted above the wait
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = HT<DT>::mfma32(make_uint4(t00.x, t00.y, t01.x, t01.y), pf[0], o);
+    o = HT<DT>::mfma32(make_uint4(t10.x, t10.y, t11.x, t11.y), pf[1], o);
+    // lane (h2, q = li): o[r] = O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h2][q] -> O patch row q
+    if (li < F) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = 32 * dt + 8 * c + 4 * h2;
+        if (dd < D) {
+          uint2 w;
+          w.x = pack2<DT>(o[4 * c + 0] * inv, o[4 * c + 1] * inv);
+          w.y = pack2<DT>(o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+          *reinterpret_cast<uint2*>(opatch + (li * D + dd) * 2) = w;
+        }
+      }
+    }
+  }
+  // ---- whole 16-byte chunks of the (frame, head) rows leave the patch ----
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (vrow[j] < F) {
+      const uint4 w = *reinterpret_cast<const uint4*>(opatch + (lane + 64 * j) * 16);
+      *reinterpret_cast<uint4*>(a.out + (row0 + (int64_t)vrow[j] * a.HW) * a.ldo + head * D + vcc[j] * 8) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Row softmax (fp32 in, half out): one block per row.
 // ------------------------------------------------------------------------------------
 template <int DT>
@@ -967,6 +1318,12 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
   const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
 #define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD, false>), grid, dim3(256), 0, st, a)
+  // d = 512: one head, no second segment, explicit scale (the VAE mid-block attention)
+#define ATTN_LAUNCH512(DT)                                                                         \
+  do {                                                                                             \
+    if (heads != 1 || Nk2 > 0 || a.prescaled) return MIMO_EINVAL;                                  \
+    hipLaunchKernelGGL((attn512_kernel<DT>), dim3((unsigned)((Nq + 31) / 32), (unsigned)B), dim3(256), 0, st, a); \
+  } while (0)
 #define ATTN_LAUNCH40(DT)                                                                          \
   do {                                                                                             \
     if (a.prescaled && !attn40_legacy())                                                           \
@@ -980,6 +1337,7 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
       case 64: ATTN_LAUNCH(MIMO_F16, 64); break;
       case 80: ATTN_LAUNCH(MIMO_F16, 80); break;
       case 160: ATTN_LAUNCH(MIMO_F16, 160); break;
+      case 512: ATTN_LAUNCH512(MIMO_F16); break;
       default: return MIMO_EINVAL;
     }
   } else if (dtype == MIMO_BF16) {
@@ -988,12 +1346,14 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
       case 64: ATTN_LAUNCH(MIMO_BF16, 64); break;
       case 80: ATTN_LAUNCH(MIMO_BF16, 80); break;
       case 160: ATTN_LAUNCH(MIMO_BF16, 160); break;
+      case 512: ATTN_LAUNCH512(MIMO_BF16); break;
       default: return MIMO_EINVAL;
     }
   } else {
     return MIMO_EDTYPE;
   }
 #undef ATTN_LAUNCH
+#undef ATTN_LAUNCH512
 #undef ATTN_LAUNCH40
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
@@ -1012,7 +1372,15 @@ extern "C" int mimo_temporal_attention(int dtype, const void* q, int64_t ldq, co
   const int64_t nb = (units + 3) / 4;
   if (nb > 0x7fffffff) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-#define TATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((temporal_attn_kernel<DT, DD>), dim3((unsigned)nb), dim3(256), 0, st, a)
+  // the second form needs 16-byte-aligned rows everywhere (every call of the UNets qualifies); MIMO_TATTN_LEGACY=1 (tune
+  // build only) keeps the first form for A/B timing
+  const bool v2 = !(ldv & 7) && !(ldo & 7) && !(reinterpret_cast<uintptr_t>(v) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15) &&
+                  !(reinterpret_cast<uintptr_t>(q) & 15) && !(reinterpret_cast<uintptr_t>(k) & 15) && !tune_env("MIMO_TATTN_LEGACY", 0);
+#define TATTN_LAUNCH(DT, DD)                                                                                          \
+  do {                                                                                                                \
+    if (v2) hipLaunchKernelGGL((temporal_attn2_kernel<DT, DD>), dim3((unsigned)nb), dim3(256), 0, st, a);             \
+    else hipLaunchKernelGGL((temporal_attn_kernel<DT, DD>), dim3((unsigned)nb), dim3(256), 0, st, a);                 \
+  } while (0)
   if (dtype == MIMO_F16) {
     switch (d) {
       case 40: TATTN_LAUNCH(MIMO_F16, 40); break;

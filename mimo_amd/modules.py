@@ -40,12 +40,47 @@ class Ctx:
         self.t_emb = None       # half [b, C0]: precomputed sinusoidal timestep embedding (UNetBase.timestep_table) or None
         self.temb = None        # fp32 [b, sum(Cout)]: every ResBlock's time_emb_proj(silu(emb)) at once
         self.attn2 = None       # fp32 [b, sum(C)]: every block's collapsed cross-attention output
+        self.band_rows = None   # VAE tiled decode: images taller than this run GroupNorm-apply + conv per row band (exact halos)
         self.stop_after = None  # write mode: block after whose bank write the rest of the graph is dead
         self.bank_rows = None   # write mode: batch rows to bank (None = all)
 
 
 class EarlyExit(Exception):
     pass
+
+
+def row_bands(H, rows):
+    """[(y0, y1)] covering [0, H) in bands of `rows` output rows (the last one may be shorter)."""
+    return [(y0, min(H, y0 + rows)) for y0 in range(0, H, rows)]
+
+
+def banded(ctx, H, W):
+    """True when an H x W image is processed in row bands: tiling is on and the image is taller than a band.  Small
+    images (the ones whose GroupNorm statistics ride in the producers' epilogues) always run whole."""
+    return bool(ctx.band_rows) and H > ctx.band_rows and H * W > ops.COLSTATS_MAX_HW
+
+
+def gn_conv3x3_banded(ctx, x, stats, gamma, beta, groups, w, cout, bias, out, *, raw_shortcut=False, residual=None,
+                      out_scale=1.0):
+    """out = conv3x3(silu(GroupNorm(x))) computed per (image, row band): the normalised half tensor exists only one band
+    (+ one halo row above and below) at a time.  `stats` are the statistics of the WHOLE images, so every output pixel
+    sees exactly the operands of the untiled launch, and every output element accumulates its K = 9 Cin products in the
+    same order: the result is bit-identical to the untiled conv (split-K, the one batch-size dependent choice, is off
+    for the band launches; the untiled launch of such a large image never splits either).
+    raw_shortcut: `w` carries the fused 1x1 shortcut over half(x) as a 10th K segment (ResnetBlock)."""
+    n, H, W, _ = x.shape
+    with ops.split_k(False):
+        for i in range(n):
+            for y0, y1 in row_bands(H, ctx.band_rows):
+                lo, hi = max(0, y0 - 1), min(H, y1 + 1)
+                a, _ = ops.group_norm_apply(x[i:i + 1, lo:hi], stats[i:i + 1], gamma, beta, groups=groups, silu=True, dtype=ctx.dtype)
+                raw = None
+                if raw_shortcut:
+                    _, raw = ops.group_norm_apply(x[i:i + 1, y0:y1], None, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
+                ops.conv2d(a, w, cout, pad=(1 if y0 == 0 else 0, 1), out_hw=(y1 - y0, W), x2=raw, bias=bias,
+                           residual=None if residual is None else residual[i:i + 1, y0:y1], out_f32=True,
+                           out_scale=out_scale, out=out[i:i + 1, y0:y1])
+    return out
 
 
 _PACK_EPOCH = [0]
@@ -129,6 +164,27 @@ class ResnetBlock(HipModule):
         """x: fp32 [n,H,W,C1]; skip: fp32 [n,H,W,C2] concatenated virtually on the channel axis."""
         p = self.packed(ctx.dtype)
         fused_sc = self.conv_shortcut is not None
+        if skip is None and self.time_emb_proj is None and banded(ctx, x.shape[1], x.shape[2]):
+            n, H, W, _ = x.shape
+            st1 = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
+            h = torch.empty((n, H, W, self.out_channels), device=x.device, dtype=torch.float32)
+            gn_conv3x3_banded(ctx, x, st1, p["g1"], p["be1"], self.groups, p["w1"], self.out_channels, p["b1"], h)
+            st2 = ops.group_norm_stats(h, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
+            out = torch.empty_like(h)
+            # conv2 reads GN2(h) per band; the fused shortcut segment reads half(x), the plain residual reads x
+            with ops.split_k(False):
+                for i in range(n):
+                    for y0, y1 in row_bands(H, ctx.band_rows):
+                        lo, hi = max(0, y0 - 1), min(H, y1 + 1)
+                        a2, _ = ops.group_norm_apply(h[i:i + 1, lo:hi], st2[i:i + 1], p["g2"], p["be2"], groups=self.groups,
+                                                     silu=True, dtype=ctx.dtype)
+                        raw = None
+                        if fused_sc:
+                            _, raw = ops.group_norm_apply(x[i:i + 1, y0:y1], None, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
+                        ops.conv2d(a2, p["w2"], self.out_channels, pad=(1 if y0 == 0 else 0, 1), out_hw=(y1 - y0, W), x2=raw,
+                                   bias=p["b2"], residual=None if fused_sc else x[i:i + 1, y0:y1], out_f32=True,
+                                   out_scale=1.0 / self.output_scale_factor, out=out[i:i + 1, y0:y1])
+            return out
         a1, raw = ops.group_norm(x, p["g1"], p["be1"], groups=self.groups, eps=self.eps, silu=True, x2=skip,
                                  dtype=ctx.dtype, want_raw=fused_sc)
         tb = None
@@ -178,8 +234,23 @@ class Upsample(HipModule):
 
     def run(self, ctx, x, output_size=None):
         p = self.packed(ctx.dtype)
-        _, xh = ops.group_norm(x, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
         n, H, W, _ = x.shape
+        if output_size is None and banded(ctx, 2 * H, 2 * W):
+            # row bands of the UPSAMPLED image (even boundaries): output rows [y0, y1) read virtual rows y0 - 1 .. y1, i.e.
+            # source rows y0 / 2 - 1 .. y1 / 2; the band's virtual image starts at source row lo, so the first virtual row
+            # the band needs is local row (y0 - 1) - 2 lo: pad_t = 2 lo + 1 - y0 (= 1 for the top band, -1 below it)
+            out = torch.empty((n, 2 * H, 2 * W, self.conv.out_channels), device=x.device, dtype=torch.float32)
+            R = max(2, ctx.band_rows // 2 * 2)
+            with ops.split_k(False):
+                for i in range(n):
+                    for y0, y1 in row_bands(2 * H, R):
+                        lo, hi = max(0, y0 // 2 - 1), min(H, y1 // 2 + 1)
+                        _, xh = ops.group_norm(x[i:i + 1, lo:hi], None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
+                        ops.conv2d(xh, p["w"], self.conv.out_channels, upsample_to=(2 * (hi - lo), 2 * W),
+                                   pad=(2 * lo + 1 - y0, 1), out_hw=(y1 - y0, 2 * W), bias=p["b"], out_f32=True,
+                                   out=out[i:i + 1, y0:y1])
+            return out
+        _, xh = ops.group_norm(x, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
         size = (2 * H, 2 * W) if output_size is None else tuple(output_size)
         return ops.conv2d(xh, p["w"], self.conv.out_channels, upsample_to=size, bias=p["b"], out_f32=True, colstats=True)
 

@@ -240,7 +240,8 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
 
 
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
-           img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0, colstats=False):
+           img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0, colstats=False,
+           out=None):
     """Channels-last implicit-GEMM conv.  x: half [n, H, W, Cin]; w: packed half [cout, ks*ks*Cin (+Cin2)].
 
     pad = (pad_top, pad_left); default (ks//2, ks//2).  out_hw defaults to the torch formula for
@@ -267,7 +268,10 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
                      imgs_per_bias_row, 0 if img_bias is None else img_bias.stride(0))
     if img_bias is not None:
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
-    out = torch.empty((n, Ho, Wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    if out is None:
+        out = torch.empty((n, Ho, Wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    else:  # a caller-owned destination (a row band of a larger tensor)
+        assert out.shape == (n, Ho, Wo, cout) and out.is_contiguous() and out.dtype == (torch.float32 if out_f32 else x.dtype)
     flags = (L.EPI_SILU if silu else 0) | (L.EPI_OUT_F32 if out_f32 else 0)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == out.shape
@@ -294,11 +298,9 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
     return with_stats(out, cs)
 
 
-def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dtype=None, want_raw=False,
-               want_norm=True):
-    """GroupNorm(+SiLU) over the virtual channel concat [x1 | x2]; inputs [n, H, W, C*] fp32 or half.
-
-    Returns (normed_half or None, raw_half or None)."""
+def group_norm_stats(x1, *, groups=32, eps=1e-5, x2=None, dtype=None):
+    """(mean, rstd) per (image, group) of the virtual channel concat [x1 | x2]: fp32 [n, groups, 2].  From the producers'
+    epilogue column statistics when both inputs carry them (no pass over HBM), otherwise one statistics pass."""
     _chk(x1, "x1")
     assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
     n = x1.shape[0]
@@ -310,38 +312,63 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
     f32 = _is_f32(x1)
     if x2 is not None:
         assert _is_f32(x2) == f32 and x2.numel() // (n * C2) == HW
-    shape = tuple(x1.shape[:-1]) + (C1 + C2,)
-    out = raw = stats = None
     cs1, cs2 = stats_of(x1), (None if x2 is None else stats_of(x2))
-    if want_norm and cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 \
+    stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
+    if cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 \
             and cs1.shape[0] * 32 == n * HW and (cs2 is None or cs2.shape[0] == cs1.shape[0]):
         # the producers' epilogues already reduced every 32-row slab: merge slabs x group columns, no pass over x
-        stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
         L.call("mimo_group_norm_stats_cols", cs1.data_ptr(), C1, _ptr(cs2), C2, n, HW, groups, float(eps),
                stats.data_ptr(), _stream())
-        out = torch.empty(shape, device=x1.device, dtype=dtype)
-    elif want_norm:
-        stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
-        C = C1 + C2
-        if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
-            # row-streaming statistics: one block per (image, pixel slice) reads whole pixel rows; the slices'
-            # (S, Q) partials are reduced in fixed order (deterministic)
-            # (the slicing is a function of the image size only: a frame's statistics must not depend on how many
-            # other frames share the launch, or the sharded long-clip mode would not reproduce the single-GPU bits)
-            split = max(1, min(256, HW // 96))
-            partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32)
-        else:
-            # one block per (image, group), pixel-sliced for large images
-            split = max(1, min(8, HW // 4096))
-            partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
-        L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
-               float(eps), stats.data_ptr(), _ptr(partials), split, _stream())
-        out = torch.empty(shape, device=x1.device, dtype=dtype)
-    if want_raw:
-        raw = torch.empty(shape, device=x1.device, dtype=dtype)
+        return stats
+    C = C1 + C2
+    if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
+        # row-streaming statistics: one block per (image, pixel slice) reads whole pixel rows; the slices'
+        # (S, Q) partials are reduced in fixed order (deterministic)
+        # (the slicing is a function of the image size only: a frame's statistics must not depend on how many
+        # other frames share the launch, or the sharded long-clip mode would not reproduce the single-GPU bits)
+        split = max(1, min(256, HW // 96))
+        partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32)
+    else:
+        # one block per (image, group), pixel-sliced for large images
+        split = max(1, min(8, HW // 4096))
+        partials = torch.empty((n * groups * split, 2), device=x1.device, dtype=torch.float32) if split > 1 else None
+    L.call("mimo_group_norm_stats", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
+           float(eps), stats.data_ptr(), _ptr(partials), split, _stream())
+    return stats
+
+
+def group_norm_apply(x1, stats, gamma, beta, *, groups=32, silu=False, x2=None, dtype=None, want_raw=False,
+                     want_norm=True):
+    """The apply pass of GroupNorm(+SiLU) with GIVEN statistics (fp32 [n, groups, 2], or None with want_norm=False: a
+    plain half cast).  x1 / x2 may be row bands [n = 1, rows, W, C] of an image whose statistics were taken over the
+    whole image (the band-tiled VAE decode).  Returns (normed_half or None, raw_half or None)."""
+    _chk(x1, "x1")
+    assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
+    n = x1.shape[0]
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    HW = x1.numel() // (n * C1)
+    if dtype is None:
+        dtype = x1.dtype if x1.dtype in _DT else torch.float16
+    f32 = _is_f32(x1)
+    shape = tuple(x1.shape[:-1]) + (C1 + C2,)
+    out = torch.empty(shape, device=x1.device, dtype=dtype) if want_norm else None
+    raw = torch.empty(shape, device=x1.device, dtype=dtype) if want_raw else None
+    if want_norm:
+        assert stats is not None and stats.is_contiguous() and stats.shape == (n, groups, 2)
     L.call("mimo_group_norm_apply", x1.data_ptr(), C1, _ptr(x2), C2, f32, dt_code(dtype), n, HW, groups,
-           _ptr(stats), _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(raw), _stream())
+           _ptr(stats) if want_norm else None, _ptr(gamma), _ptr(beta), int(silu), _ptr(out), _ptr(raw), _stream())
     return out, raw
+
+
+def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dtype=None, want_raw=False,
+               want_norm=True):
+    """GroupNorm(+SiLU) over the virtual channel concat [x1 | x2]; inputs [n, H, W, C*] fp32 or half.
+
+    Returns (normed_half or None, raw_half or None)."""
+    stats = group_norm_stats(x1, groups=groups, eps=eps, x2=x2, dtype=dtype) if want_norm else None
+    return group_norm_apply(x1, stats, gamma, beta, groups=groups, silu=silu, x2=x2, dtype=dtype, want_raw=want_raw,
+                            want_norm=want_norm)
 
 
 def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0, out_f32=False):

@@ -13,8 +13,11 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32
+from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32, banded, gn_conv3x3_banded
 from .packing import pack_conv, pad_vec
+
+
+FLASH_HEAD_DIMS = (64, 80, 160, 512)  # single-head widths mimo_attention has a kernel for
 
 
 class _VaeAttn(nn.Module):
@@ -48,21 +51,33 @@ class VaeMidBlock(HipModule):
         x = self.resnets[0].run(ctx, x)
         n, H, W, C = x.shape
         N = H * W
-        Np = (N + 7) // 8 * 8  # key count padded to the 16-byte operand granule; padded keys get probability 0
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=False, dtype=ctx.dtype)
         qkv = ops.gemm(g.view(-1, C), p["qkv_w"], bias=p["qkv_b"]).view(n, N, 3 * C)
-        o = torch.empty((n, N, C), device=x.device, dtype=ctx.dtype)
-        kp = torch.zeros((Np, C), device=x.device, dtype=ctx.dtype)
-        vt = torch.zeros((C, Np), device=x.device, dtype=ctx.dtype)
-        pr = torch.zeros((N, Np), device=x.device, dtype=ctx.dtype)
-        for i in range(n):  # d = 512 single head: scores / softmax / P.V as GEMM + row-softmax + GEMM
+        if C in FLASH_HEAD_DIMS:
+            # one head of d = C (512 for sd-vae-ft-mse): flash attention over the N tokens of every image in ONE launch
+            # (attn512_kernel: the head dimension split over the four waves of a block) — no N x N scores in HBM
+            o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1)
+        else:
+            o = self._attention_unfused(ctx, qkv, n, N, C)
+        y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], residual=x.view(-1, C), out_f32=True).view(n, H, W, C)
+        return self.resnets[1].run(ctx, y)
+
+
+    def _attention_unfused(self, ctx, qkv, n, N, C):
+        """Widths without a flash kernel (not reached by sd-vae-ft-mse): scores / softmax / P.V as GEMM + row softmax +
+        GEMM per image, the N x N score matrix in HBM."""
+        Np = (N + 7) // 8 * 8  # key count padded to the 16-byte operand granule; padded keys get probability 0
+        o = torch.empty((n, N, C), device=qkv.device, dtype=ctx.dtype)
+        kp = torch.zeros((Np, C), device=qkv.device, dtype=ctx.dtype)
+        vt = torch.zeros((C, Np), device=qkv.device, dtype=ctx.dtype)
+        pr = torch.zeros((N, Np), device=qkv.device, dtype=ctx.dtype)
+        for i in range(n):
             kp[:N].copy_(qkv[i, :, C:2 * C])
             vt[:, :N].copy_(qkv[i, :, 2 * C:].t())
             s = ops.gemm(qkv[i, :, :C], kp, out_f32=True)
             ops.softmax_rows(s[:, :N], ctx.dtype, scale=C ** -0.5, out=pr[:, :N])
             ops.gemm(pr, vt, out=o[i])
-        y = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], residual=x.view(-1, C), out_f32=True).view(n, H, W, C)
-        return self.resnets[1].run(ctx, y)
+        return o
 
 
 class _EncDownBlock(nn.Module):
@@ -144,6 +159,10 @@ class Decoder(HipModule):
         x = self.mid_block.run(ctx, x)
         for blk in self.up_blocks:
             x = blk.run(ctx, x)
+        if banded(ctx, x.shape[1], x.shape[2]):
+            st = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
+            out = torch.empty(tuple(x.shape[:3]) + (4,), device=x.device, dtype=torch.float32)
+            return gn_conv3x3_banded(ctx, x, st, p["g"], p["b"], self.groups, p["co_w"], 4, p["co_b"], out)
         a, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
         return ops.conv2d(a, p["co_w"], 4, bias=p["co_b"], out_f32=True)  # [n,H,W,4], channel 3 is padding
 
@@ -182,6 +201,7 @@ class AutoencoderKL(HipModule):
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.compute_dtype = torch.float16
         self.latent_channels = latent_channels
+        self.tile_band_rows = None
 
     @property
     def dtype(self):
@@ -190,6 +210,18 @@ class AutoencoderKL(HipModule):
     @property
     def device(self):
         return self.quant_conv.weight.device
+
+    def enable_tiling(self, band_rows=64):
+        """Tiled decode (BASELINE configs[4]: "VAE tiled decode"), result-identical to the untiled one: the reference has
+        no blended tiling (only enable_vae_slicing, pipeline :82-86), so tiles must carry exact halos.  Every
+        GroupNorm+SiLU -> 3x3 conv pair of the decoder levels taller than `band_rows` runs per row band with one halo
+        row on each side (channels-last: a row band of an image is one contiguous slab), the nearest-x2 up-sampling
+        convs likewise; GroupNorm statistics stay global per image (they have to: that is what makes the tiles exact).
+        The normalised half intermediates then exist one band at a time."""
+        self.tile_band_rows = int(band_rows)
+
+    def disable_tiling(self):
+        self.tile_band_rows = None
 
     def enable_slicing(self):  # the batched path already streams frames through each layer
         pass
@@ -256,6 +288,7 @@ class AutoencoderKL(HipModule):
         """z_tok: half [n,h,w,8] (4 latent channels + 4 zero) -> fp32 tokens [n,8h,8w,4] (RGB + 1 pad channel)."""
         dt = self.compute_dtype
         ctx = Ctx(dt, z_tok.shape[0], 1)
+        ctx.band_rows = self.tile_band_rows
         p = self.packed(dt)
         n, h, w, c = z_tok.shape
         z8 = ops.gemm(z_tok.view(-1, c), p["pq_w"], bias=p["pq_b"]).view(n, h, w, 8)  # channels 4..7 stay zero

@@ -154,7 +154,13 @@ def test_hip_vae_784_frame_vs_oracle_golden(full_models):
     e_dec = rel_l2(video, G["video_frame"])
     enc = (vae.encode(img.clamp(-1, 1)).latent_dist.mean.float() * 0.18215).cpu()
     e_enc = rel_l2(enc, G["reencoded_latent"])
-    line = f"VAE 784x784 frame fp16 vs oracle fp32: decode rel_l2={e_dec:.2e}, encode(decoded) rel_l2={e_enc:.2e}"
+    vae.enable_tiling(96)  # 784 = 8 x 96 + 16: a ragged last band at the full-resolution levels
+    try:
+        tiled = vae.decode((G["latent"] / 0.18215).to(dev)).sample.float()
+    finally:
+        vae.disable_tiling()
+    assert torch.equal(tiled, img), "tiled VAE decode must be bit-identical to the untiled one"
+    line = f"VAE 784x784 frame fp16 vs oracle fp32: decode rel_l2={e_dec:.2e}, encode(decoded) rel_l2={e_enc:.2e}; tiled decode (96-row bands) bit-identical"
     print(line)
     _report(line)
     assert e_dec < 1e-3 and e_enc < 2e-3  # the encoder runs on the product's own decoded image (its error is included)

@@ -446,3 +446,154 @@ def test_mask_mode_matches_reference_get_mask():
         ys = sorted(rnd.choice([-2, 0, 7, 50, 95, 96, 100]) for _ in range(2))
         bbox = (xs[0], xs[1], ys[0], ys[1])
         assert ns["get_mask"](masks, bbox, Img) == E.get_mask(masks, bbox, Img)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ROI-clip segmentation / padding / mask resize (mimo_amd/template.py, mimo_amd/cvops.py)
+# ------------------------------------------------------------------------------------------------------------------
+def _synthetic_template(n=40, H=240, W=320, seed=0):
+    """Pose frames with a textured person blob that walks right and grows (so the clip cutter fires), random video and
+    background frames."""
+    import numpy as np
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    pose, vid, bk = [], [], []
+    for i in range(n):
+        f = np.zeros((H, W, 3), np.uint8)
+        cx, cy = 60 + 4 * i, H // 2
+        hw = 20 + (0 if i < 20 else 3 * (i - 20))
+        hh = 50 + (0 if i < 25 else 2 * (i - 25))
+        y0, y1, x0, x1 = max(0, cy - hh), min(H, cy + hh), max(0, cx - hw), min(W, cx + hw)
+        f[y0:y1, x0:x1] = rs.randint(0, 255, (y1 - y0, x1 - x0, 3))   # includes dark pixels: holes for clean_mask
+        f[rs.randint(0, H, 6), rs.randint(0, W, 6)] = 200               # isolated noise pixels: removed by the 2x2 opening
+        pose.append(Image.fromarray(f))
+        vid.append(Image.fromarray(rs.randint(0, 255, (H, W, 3), dtype=np.uint8)))
+        bk.append(Image.fromarray(rs.randint(0, 255, (H, W, 3), dtype=np.uint8)))
+    return pose, vid, bk
+
+
+def test_cvops_primitives_against_independent_implementations():
+    """mimo_amd.cvops vs scipy.ndimage / first-principles NumPy (oracle/cv2_standin.py): grey conversion, rectangular
+    morphology incl. the even 2x2 element, bounding rectangle, constant border."""
+    import numpy as np
+    from mimo_amd import cvops
+    from oracle import cv2_standin as cv2
+    rs = np.random.RandomState(1)
+    img = rs.randint(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(cvops.rgb2gray(img), cv2.cvtColor(img, cv2.COLOR_RGB2GRAY))
+    assert int(cvops.rgb2gray(np.full((1, 1, 3), 255, np.uint8))[0, 0]) == 255
+    for dens in (0.02, 0.3, 0.7):
+        m = (rs.rand(41, 29) < dens).astype(np.uint8) * 255
+        for op, code in (("close", cv2.MORPH_CLOSE), ("open", cv2.MORPH_OPEN)):
+            for k in (2, 5):
+                ref = cv2.morphologyEx(m, code, cv2.getStructuringElement(cv2.MORPH_RECT, (k, k)))
+                assert np.array_equal(cvops.morphology_rect(m, op, k), ref), (op, k)
+        assert cvops.bounding_rect(m) == cv2.boundingRect(m)
+    assert cvops.bounding_rect(np.zeros((5, 5), np.uint8)) == (0, 0, 0, 0)
+    z = np.zeros((9, 9), np.uint8)
+    z[2:5, 3:8] = 1
+    assert cvops.bounding_rect(z) == (3, 2, 5, 3)
+    a = cvops.copy_make_border(img, 3, 4, 5, 6, [255, 0, 7])
+    assert np.array_equal(a, cv2.copyMakeBorder(img, 3, 4, 5, 6, cv2.BORDER_CONSTANT, value=[255, 0, 7]))
+    assert a.shape == (44, 64, 3) and np.array_equal(a[3:40, 5:58], img) and tuple(a[0, 0]) == (255, 0, 7)
+
+
+def test_resize_area_properties():
+    """cv2.resize(..., INTER_AREA) restated (cv2 absent: pinned by construction): an integer ratio is the exact block mean,
+    a fractional reduction equals the area integral of the piecewise-constant source computed from first principles in
+    float64 (PIL's BOX filter is NOT that: it weights whole pixels by their centres), constants stay constant on every path,
+    the enlarging path interpolates inside the source range."""
+    import numpy as np
+    from PIL import Image
+    from mimo_amd import cvops
+    rs = np.random.RandomState(2)
+    src = rs.rand(96, 120).astype(np.float32)
+    out = cvops.resize_area(src, (40, 24))                                  # ratios 3 and 4
+    ref = src.reshape(24, 4, 40, 3).astype(np.float64).mean(axis=(1, 3))
+    assert out.shape == (24, 40) and out.dtype == np.float32 and np.abs(out - ref).max() < 1e-6
+    out = cvops.resize_area(src, (47, 33))                                  # fractional reduction
+    def overlap(ssize, dsize):  # [dsize, ssize] exact overlap lengths of destination cells with source pixels (float64)
+        sc = ssize / dsize
+        lo = np.arange(dsize)[:, None] * sc
+        px = np.arange(ssize)[None, :]
+        return np.clip(np.minimum(lo + sc, px + 1) - np.maximum(lo, px), 0, None) / sc
+    area = overlap(96, 33) @ src.astype(np.float64) @ overlap(120, 47).T       # the area integral from first principles
+    assert np.abs(out - area).max() < 1e-5
+    for size in ((40, 24), (47, 33), (150, 200), (47, 200)):
+        c = cvops.resize_area(np.full((96, 120), 0.375, np.float32), size)
+        assert c.shape == (size[1], size[0]) and np.abs(c - 0.375).max() < 1e-6
+    up = cvops.resize_area(src, (150, 200))
+    assert up.min() >= src.min() - 1e-6 and up.max() <= src.max() + 1e-6
+    u8 = cvops.resize_area(rs.randint(0, 256, (64, 64, 3), dtype=np.uint8), (16, 16))
+    assert u8.dtype == np.uint8 and u8.shape == (16, 16, 3)
+
+
+def test_template_clip_segmentation_properties():
+    """crop_human_clip_auto_context + pad_img + prepare_clips + clip_masks on a synthetic template: every frame is covered,
+    consecutive clips share `overlay` frames, crops have their clip's box size, padded frames are squares of a multiple of
+    16 whose paddings add up, masks have the un-padded crop size."""
+    import numpy as np
+    from mimo_amd import template as T
+    from mimo_amd.edit import MASK_MODE
+    pose, vid, bk = _synthetic_template()
+    pc, vc, bc, bbox_clip, ctx, boxes = T.crop_human_clip_auto_context(pose, vid, bk, 4)
+    assert len(ctx) >= 2 and ctx[0][0] == 0 and ctx[-1][-1] == len(pose) - 1
+    for a, b in zip(ctx[:-1], ctx[1:]):
+        assert b[0] == a[-1] + 1 - min(4, len(a))                           # the overlap the compositing cross-fades over
+    assert len(pc) == len(vc) == len(bc) == sum(len(c) for c in ctx) and len(bbox_clip) == len(pose)
+    k0 = 0
+    for c, (x, x_max, y, y_max) in zip(ctx, boxes):
+        for j in range(len(c)):
+            assert pc[k0 + j].size == (x_max - x, y_max - y) == vc[k0 + j].size == bc[k0 + j].size
+        k0 += len(c)
+    pl, bl, pads, padv = T.prepare_clips(pc, bc)
+    for im_p, im_b, (ph, pw), (t, b, l, r), crop in zip(pl, bl, pads, padv, bc):
+        assert im_p.size == im_b.size == (pw, ph) and ph == pw and ph % 16 == 0
+        assert t + b + crop.size[1] == ph and l + r + crop.size[0] == pw and abs(t - b) <= 1 and abs(l - r) <= 1
+        assert np.array_equal(np.asarray(im_b)[t:ph - b, l:pw - r], np.asarray(crop))
+        assert int(np.asarray(im_p)[0, 0].sum()) == 0 or t == 0 == l          # pose frames are padded black
+    rs = np.random.RandomState(3)
+    mask_list = [rs.rand(64, 64).astype(np.float32) for _ in MASK_MODE]
+    masks = T.clip_masks(mask_list, ctx, boxes, pads, padv, pose[0].size)
+    assert len(masks) == len(pc)
+    for m, crop in zip(masks, bc):
+        assert m.dtype == np.float32 and m.shape == (crop.size[1], crop.size[0])
+
+
+@pytest.mark.reference
+def test_template_functions_match_reference_tools_util():
+    """mimo_amd.template == the reference's own tools/util.py functions (pad_img, crop_img, extract_mask_sdc, clean_mask,
+    crop_img_sdc, bbox_div2, bbox_pad, update_clip, compute_area_ratio, crop_human_clip_auto_context), executed from the
+    reference source via `ast` with oracle/cv2_standin.py in place of the absent cv2: same crops (bit for bit), same
+    per-frame boxes, same context_list / bbox_clip_list."""
+    import ast
+    import numpy as np
+    from PIL import Image
+    from mimo_amd import template as T
+    from oracle import cv2_standin
+    names = {"pad_img", "crop_img", "extract_mask_sdc", "clean_mask", "crop_img_sdc", "init_bbox", "bbox_div2", "bbox_pad",
+             "update_clip", "compute_area_ratio", "crop_human_clip_auto_context"}
+    tree = ast.parse(open("/root/reference/tools/util.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in keep} == names
+    ns = {"np": np, "cv2": cv2_standin, "Image": Image}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "tools/util.py", "exec"), ns)
+    for seed, n in ((0, 40), (5, 17), (9, 3)):
+        pose, vid, bk = _synthetic_template(n=n, seed=seed)
+        ref = ns["crop_human_clip_auto_context"](pose, vid, bk, 4)
+        out = T.crop_human_clip_auto_context(pose, vid, bk, 4)
+        assert [list(c) for c in out[4]] == [list(c) for c in ref[4]]
+        assert [tuple(int(v) for v in b) for b in out[5]] == [tuple(int(v) for v in b) for b in ref[5]]
+        assert [[int(v) for v in b] for b in out[3]] == [[int(v) for v in b] for b in ref[3]]
+        for a_list, b_list in zip(out[:3], ref[:3]):
+            assert len(a_list) == len(b_list)
+            assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(a_list, b_list))
+        for crop in out[2][:5]:
+            for color in ([255, 255, 255], [0, 0, 0]):
+                a, pa = T.pad_img(np.asarray(crop), color)
+                b, pb = ns["pad_img"](np.asarray(crop), color)
+                assert np.array_equal(a, b) and list(pa) == list(pb)
+    img = np.asarray(_synthetic_template(n=1, seed=4)[0][0])
+    m = ns["clean_mask"](ns["extract_mask_sdc"](img))
+    assert np.array_equal(T.clean_mask(T.extract_mask_sdc(img)), m)
+    assert np.array_equal(T.crop_img(img, m), ns["crop_img"](img, m))

@@ -380,6 +380,25 @@ def test_attention_self_plus_bank(dev, dtype, d, N, Nb):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,B,spike", [(64, 1, 0), (100, 3, 0), (1024, 2, 0), (333, 2, 5), (4096, 1, 0)])
+def test_attention_single_head_d512(dev, dtype, N, B, spike):
+    """The VAE mid-block attention: ONE head of d = 512 over the N tokens of an image (attn512_kernel: head dimension split
+    over the four waves of a block, partial scores exchanged through LDS).  Ragged N (not a multiple of the 32-query block
+    or the 64-key tile), several images per launch, and a late key spike that moves the running max in a later tile."""
+    from mimo_amd import ops
+    C = 512
+    qkv = rnd((B, N, 3 * C), dev, dtype, 21, 0.5)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    if spike:
+        k[B - 1, N - 9] = (q[B - 1, 7].float() * spike).to(dtype)
+    out = ops.attention(q, k, v, 1)
+    ref = sdpa_ref(q, k, v, 1)
+    assert rel_l2(out.float(), ref) < 2.5 * OUT_TOL[dtype]
+    for bi in range(B):  # every image separately: a batch-stride mistake would hide in the aggregate
+        assert rel_l2(out[bi].float(), ref[bi]) < 2.5 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_forced_rescale(dev, dtype):
     """Spike a late key so the running max jumps in a later KV tile (online-softmax rescale path)."""
     from mimo_amd import ops
@@ -427,7 +446,8 @@ def test_attention_prescaled_q(dev, dtype, d, N, Nb, spike):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("d,Fr,HW", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 5), (160, 3, 7)])
+@pytest.mark.parametrize("d,Fr,HW", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 5), (160, 3, 7), (64, 17, 3), (40, 1, 2),
+                                     (80, 24, 33)])
 def test_temporal_attention(dev, dtype, d, Fr, HW):
     from mimo_amd import ops
     heads, b = 8, 2

@@ -1,0 +1,76 @@
+"""Round-3 micro A/B on one MI355X (tune build: the legacy kernels stay selectable through the environment).
+  python tools/r3_micro.py [temporal] [vae_attn]
+temporal : temporal attention, first form (2-byte V gathers) vs second form (16-byte accesses + transposed LDS reads)
+vae_attn : VAE mid-block attention at d = 512: flash kernel vs GEMM + row softmax + GEMM per image"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MIMO_HIP_LIB", os.path.join(ROOT, "mimo_amd", "libmimo_hip_tune.so"))
+from mimo_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def ab(fn, env_a, env_b, rounds=3):
+    best = [float("inf"), float("inf")]
+    for _ in range(rounds):
+        for i, env in enumerate((env_a, env_b)):
+            for k in set(env_a) | set(env_b):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            best[i] = min(best[i], timeit(fn))
+    for k in set(env_a) | set(env_b):
+        os.environ.pop(k, None)
+    return best
+
+
+def temporal(dev, dt):
+    print("temporal attention (b = 2, F = 24): first form vs second form; GB/s = (3 reads + 1 write) x rows x C x 2 B")
+    for (HW, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280), (9216, 320)]:
+        b, F, heads = 2, 24, 8
+        M = b * F * HW
+        qkv = torch.randn(M, 3 * C, device=dev).to(dt)
+        fn = lambda: ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], b, F, HW, heads)
+        old, new = ab(fn, {"MIMO_TATTN_LEGACY": "1"}, {})
+        byt = 4 * M * C * 2
+        print(f"  HW {HW:5d} C {C:5d}: first {old:7.3f} ms ({byt/old/1e6:7.0f} GB/s)   second {new:7.3f} ms ({byt/new/1e6:7.0f} GB/s)", flush=True)
+
+
+def vae_attn(dev, dt):
+    from mimo_amd.modules import Ctx
+    from mimo_amd.vae import VaeMidBlock
+    print("VAE mid-block attention core, d = 512, one head: flash vs unfused (per launch group of n images)")
+    blk = VaeMidBlock(512, 32, 1e-6).to(dev)
+    for (n, N) in [(8, 4096), (4, 9216)]:
+        C = 512
+        qkv = torch.randn(n, N, 3 * C, device=dev).to(dt) * 0.3
+        ctx = Ctx(dt, n, 1)
+        f1 = lambda: ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1)
+        f2 = lambda: blk._attention_unfused(ctx, qkv, n, N, C)
+        t1, t2 = timeit(f1, iters=5, warm=1), timeit(f2, iters=5, warm=1)
+        fl = 4 * n * N * N * C
+        print(f"  n {n} N {N}: flash {t1:8.3f} ms ({fl/t1/1e9:6.0f} TF/s)   unfused {t2:8.3f} ms ({fl/t2/1e9:6.0f} TF/s)", flush=True)
+        a, bb = f1().float(), f2().float()
+        print(f"     rel_l2(flash, unfused) = {float((a - bb).norm() / bb.norm()):.2e}")
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    what = sys.argv[1:] or ["temporal", "vae_attn"]
+    for w in what:
+        {"temporal": temporal, "vae_attn": vae_attn}[w](dev, torch.float16)
