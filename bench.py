@@ -135,22 +135,32 @@ def measure_forward(pipe, dev, dtype, size, iters=3):
     return st.elapsed_time(en) / iters * 1e-3, flops, launches, fam
 
 
+def lib_hash():
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "mimo_amd", "libmimo_hip.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(family):
     """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     over tools/profile_forward.py (same models, same shapes; PMC passes cannot run inside the timed region).
     None when no summary has been committed for this build (tools/pmc_traffic.py writes it)."""
-    for name in ("r2_pmc_forward_traffic.json", "r1_pmc_forward_traffic.json"):  # newest committed summary first
+    for name in ("r3_pmc_forward_traffic.json", "r2_pmc_forward_traffic.json", "r1_pmc_forward_traffic.json"):  # newest first
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             d = json.load(open(path))[family]
+            full = json.load(open(path))
             return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
-                    "write": d["write_bytes_per_launch"], "source": "profiles/" + name}
+                    "write": d["write_bytes_per_launch"], "source": "profiles/" + name,
+                    "library_sha256_16": full.get("library_sha256_16"), "library_sha256_16_now": lib_hash()}
         except Exception:
             continue
     return None
 
 
-def cpu_baseline(clip_flops, frames, budget_s=25.0):
+def cpu_baseline(clip_flops, frames, budget_s=25.0, config2=False):
     """The reference's CPU PyTorch path timed on this host: ONE denoising-UNet forward of the FULL-SIZE model at
     BASELINE configs[0] size (latent 32x32, 2 x 8 frames: ~3.3 TFLOP, seconds per forward), FLOPs counted by torch's
     FlopCounterMode, extrapolated to the whole clip's executed FLOPs.  Where /root/reference is mounted (this
@@ -189,7 +199,7 @@ def cpu_baseline(clip_flops, frames, budget_s=25.0):
                 mod.pe.copy_(OM.PositionalEncoding(mod.pe.shape[-1], mod.pe.shape[1]).pe)
     m.eval()
     build_s = time.time() - t0
-    hw, F = 32, 8
+    hw, F = (64, 24) if config2 else (32, 8)
     x = torch.randn(2, 8, F, hw, hw)
     ehs = torch.randn(2, 1, 768)
     pose = torch.randn(2, 320, F, hw, hw)
@@ -200,22 +210,32 @@ def cpu_baseline(clip_flops, frames, budget_s=25.0):
         return m(x, torch.tensor(499), ehs, pose_cond_fea=pose)
 
     with torch.no_grad():
-        with FlopCounterMode(display=False) as fc:
-            fwd()  # warm-up + FLOP count
-        sample_flops = fc.get_total_flops()
-        n, t1 = 0, time.time()
-        while n < 1 or (time.time() - t1 < budget_s and n < 5):
-            fwd()
-            n += 1
-        dt = (time.time() - t1) / n
+        if config2:  # one forward is about a minute: the counted pass IS the timed pass (no warm-up)
+            t1 = time.time()
+            with FlopCounterMode(display=False) as fc:
+                fwd()
+            dt, n = time.time() - t1, 1
+            sample_flops = fc.get_total_flops()
+        else:
+            with FlopCounterMode(display=False) as fc:
+                fwd()  # warm-up + FLOP count
+            sample_flops = fc.get_total_flops()
+            n, t1 = 0, time.time()
+            while n < 1 or (time.time() - t1 < budget_s and n < 5):
+                fwd()
+                n += 1
+            dt = (time.time() - t1) / n
     cpu_flops_per_s = sample_flops / dt
     what = "the reference's src/models UNet3DConditionModel (oracle/diffusers_standin.py)" if kind == "reference" \
         else "oracle.models.UNet3DConditionModel (port of the reference's PyTorch path)"
     return dict(value=frames / (clip_flops / cpu_flops_per_s), unit="frames/s", cores=cores, kind=kind,
                 sample=(f"{what}, full size, fp32, {cores} threads: denoising forward on 2x{F} frames at latent {hw}x{hw} "
-                        f"(BASELINE configs[0] size), {n} timed: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => "
+                        f"(BASELINE configs[{1 if config2 else 0}] size), {n} timed: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => "
                         f"{cpu_flops_per_s/1e12:.3f} TFLOP/s; extrapolated to the clip's {clip_flops/1e12:.1f} executed TFLOP "
-                        f"(model build {build_s:.0f} s untimed)"))
+                        f"(model build {build_s:.0f} s untimed)"
+                        + ("" if config2 else "; configs[0] -> configs[1] shape ratio of the CPU rate, measured on the reference's own "
+                           "code in the build container (8 cores): 0.50 -> 0.483 TFLOP/s = 0.96 (SURVEY 8c); on a 32-thread MI355X host: "
+                           "profiles/r3_cpu_baseline_config2.json")))
 
 
 def bf16_record(pipe, dev, inp, a, fp16_forward_out):
@@ -240,6 +260,34 @@ def bf16_record(pipe, dev, inp, a, fp16_forward_out):
     out = forward_output(pipe, dev, dt, a.size)
     rel = float((out.float() - fp16_forward_out.float()).norm() / fp16_forward_out.float().norm())
     return {"value": a.frames / el, "unit": "frames/s", "ms_per_step": el * 1e3, "steps": 1, "forward_rel_l2_vs_fp16": rel}
+
+
+def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16):
+    """BASELINE configs[4] names "fp8 MFMA attention QK" (accuracy reported, not gated): the same
+    denoising forward with every spatial attention's Q.K^T on the e4m3 MFMA (mimo_attention_fp8qk, opt-in through
+    ops.fp8_qk): rel-L2 of its output against the 16-bit forward of the same inputs, and its time.  The non-scaled fp8 MFMA
+    of gfx950 has the f16 rate, and the fp8 variant lives in the generic flash kernel (the d = 40 production kernel keeps
+    its integer running max in an f16 k-slot that e4m3 cannot hold), so it is expected to be SLOWER: the record says by how much."""
+    from mimo_amd import ops
+    with ops.fp8_qk(True):
+        out = forward_output(pipe, dev, dtype, size)
+        torch.cuda.synchronize()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(2):
+            forward_output(pipe, dev, dtype, size)
+        en.record()
+        torch.cuda.synchronize()
+    rel = float((out.float() - fp16_forward_out.float()).norm() / fp16_forward_out.float().norm())
+    st2, en2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st2.record()
+    for _ in range(2):
+        forward_output(pipe, dev, dtype, size)
+    en2.record()
+    torch.cuda.synchronize()
+    return {"forward_rel_l2_vs_16bit_qk": rel, "forward_ms_fp8_qk": st.elapsed_time(en) / 2,
+            "forward_ms_16bit_qk_same_harness": st2.elapsed_time(en2) / 2,
+            "note": "opt-in (ops.fp8_qk / mimo_attention_fp8qk); both timings include the reference-UNet bank set-up of the harness"}
 
 
 def forward_output(pipe, dev, dtype, size):
@@ -267,6 +315,24 @@ def forward_output(pipe, dev, dtype, size):
     return out
 
 
+def shard_plan(a, frames, world):
+    """--shard-windows: what every rank runs per denoising step (whole windows as b = 2 forwards, single CFG halves as b = 1
+    forwards), the plan's cost per rank in batched-window units and the speed-up it bounds (mimo_amd.pipeline.plan_items)."""
+    if not a.shard_windows:
+        return {}
+    from mimo_amd.context import get_context_scheduler
+    from mimo_amd.pipeline import plan_items, plan_load
+    nw = len(get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4))
+    cfg = a.guidance > 1.0
+    load, bound = plan_load(nw, cfg, world)
+    return {"shard_plan": {"windows": nw, "units": nw * (2 if cfg else 1),
+                           "per_rank_items": [[("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in r]
+                                              for r in plan_items(nw, cfg, world)],
+                           "per_rank_cost": [round(x, 2) for x in load], "speedup_bound": round(bound, 2),
+                           "collective": "slot-wise all_gather_into_tensor of fp32 [24, h, w, 4] unit predictions (RCCL), "
+                                         "exposed_gather_ms = HIP-event time of the final exchange wait per clip"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,10 +350,15 @@ def main():
                     "(default: the pipeline's setting, 2; 1 = one stream; only clips with > 24 frames have several windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 sub-record (one extra clip + one forward)")
+    ap.add_argument("--fp8-qk", action="store_true", help="add the fp8 Q.K^T sub-record (BASELINE configs[4]): accuracy and time "
+                    "of one denoising forward with the spatial attentions' Q.K^T on the e4m3 MFMA")
+    ap.add_argument("--tile-vae", type=int, default=0, help="VAE tiled decode (exact row bands of this many rows; BASELINE configs[4])")
+    ap.add_argument("--cpu-baseline-config2", action="store_true", help="time the CPU baseline at configs[1] shapes (one forward "
+                    "on 2 x 24 frames at latent 64 x 64: about a minute on 32 threads) instead of configs[0] shapes")
     ap.add_argument("--cpu-baseline-only", type=float, default=0.0, help=argparse.SUPPRESS)  # child mode: clip FLOPs
     a = ap.parse_args()
     if a.cpu_baseline_only > 0:
-        print(json.dumps(cpu_baseline(a.cpu_baseline_only, a.frames)), flush=True)
+        print(json.dumps(cpu_baseline(a.cpu_baseline_only, a.frames, config2=a.cpu_baseline_config2)), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -310,6 +381,8 @@ def main():
     pipe.use_graphs = a.graphs and not pipe.shard_windows
     if a.window_streams is not None:
         pipe.window_streams = a.window_streams
+    if a.tile_vae:
+        pipe.vae.enable_tiling(a.tile_vae)
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
 
     host_video = torch.empty((1, 3, frames, a.size, a.size), dtype=torch.float32, pin_memory=True)
@@ -359,7 +432,8 @@ def main():
         out = {
             "metric": f"denoised frames/sec ({a.size}x{a.size}, {a.frames}f clip, {a.ddim_steps} DDIM steps)", "value": total_frames / (elapsed / a.steps),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if a.shard_windows else "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[3]: ONE {a.size}x{a.size} clip of {frames} frames sharded {a.frames} f/GPU over {world} GPUs "
                                     f"({len(range(0, frames, 20)) if frames > 24 else 1} context windows x 2 CFG halves dealt over the ranks, slot-wise "
                                     f"RCCL all_gather per step), " if a.shard_windows else
@@ -369,7 +443,8 @@ def main():
                                    f"the device-to-host copy of the video inside the timed region",
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),
                        "kernel_launches_per_clip": clip_launches,
-                       "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs)},
+                       "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs),
+                       "vae_tile_rows": a.tile_vae or None, **shard_plan(a, frames, world)},
             # dominant kernel = gemm_kernel (implicit-GEMM convs + linears, ~2/3 of the forward): algorithmic FLOPs of all
             # its launches in one denoising forward / the sum of their HIP-event durations
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel", "achieved": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,
@@ -388,12 +463,19 @@ def main():
                 out["bf16"] = bf16_record(pipe, dev, inp, a, forward_output(pipe, dev, dtype, a.size))
             except Exception as e:  # informational sub-record: never lose the headline line
                 out["bf16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if a.fp8_qk and world == 1:
+            try:
+                out["fp8_qk"] = fp8_qk_record(pipe, dev, dtype, a.size, forward_output(pipe, dev, dtype, a.size), t_fwd)
+            except Exception as e:
+                out["fp8_qk"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             import subprocess
             try:  # child process with a hard wall-clock bound: the baseline is informational, never lose the GPU line
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
-                                    str(float(clip_flops or fwd_flops * a.ddim_steps)), "--frames", str(a.frames)],
-                                   capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+                                    str(float(clip_flops or fwd_flops * a.ddim_steps)), "--frames", str(a.frames)]
+                                   + (["--cpu-baseline-config2"] if a.cpu_baseline_config2 else []),
+                                   capture_output=True, text=True, timeout=600 if a.cpu_baseline_config2 else 240,
+                                   env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
                 out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": min(os.cpu_count(), 32), "kind": "port",

@@ -196,7 +196,9 @@ int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C,
  *   (src/models/mutual_self_attention.py:154-197: cond rows attend [self || bank], uncond
  *   rows attend self) and in write mode / plain self-attention (:137-147).
  *   q,k,v: half16 token-major [B, Nq|Nk, ld*] with head h at columns [h*d, (h+1)*d);
- *   k2,v2: half16 [Nk2, ld*2] (nullable).  out: half16 [B, Nq, ldo].  d % 8 == 0, d <= 160.
+ *   k2,v2: half16 [Nk2, ld*2] (nullable).  out: half16 [B, Nq, ldo].  d in {40, 64, 80, 160}, or d = 512 with
+ *   heads = 1 and no second segment: the single-head mid-block attention of the VAE (diffusers UNetMidBlock2D
+ *   Attention over the H*W latent tokens; AutoencoderKL, pipeline_pose2vid_long_edit_bkfill_roiclip.py:120,430).
  *   scale > 0: softmax(scale * q.k^T).  scale <= 0: q is ALREADY multiplied by scale * log2(e) (the
  *   caller folded it into W_q); for d = 40 this selects the kernel variant whose softmax has no
  *   per-score multiply/subtract (the running max rides in a spare MFMA k-slot).
@@ -205,6 +207,14 @@ int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t
                    int64_t ldv, const void* k2, int64_t ldk2, const void* v2, int64_t ldv2, void* out,
                    int64_t ldo, int B, int Nq, int Nk, int Nk2, int seg2_first_batch, int heads, int d,
                    float scale, void* stream);
+/* The same operation with Q.K^T on the fp8 (e4m3, OCP) MFMA — BASELINE configs[4] "fp8 MFMA attention QK", opt-in,
+ * accuracy reported, not gated.  Q and K are converted to fp8 inside the kernel (K once per tile while
+ * it is staged, Q once per block); softmax and P.V stay on half operands.  d in {40, 80, 160}.  Same arguments as
+ * mimo_attention (same reference op: src/models/mutual_self_attention.py:154-197). */
+int mimo_attention_fp8qk(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                         int64_t ldv, const void* k2, int64_t ldk2, const void* v2, int64_t ldv2, void* out,
+                         int64_t ldo, int B, int Nq, int Nk, int Nk2, int seg2_first_batch, int heads, int d,
+                         float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Temporal attention over the frame axis without materialising '(b f) d c -> (b d) f c'

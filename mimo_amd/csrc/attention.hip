@@ -39,7 +39,25 @@ struct AttnArgs {
   int prescaled;  // Q already carries softmax_scale * log2(e) (folded into W_q by the caller)
 };
 
-template <int DT, int D, bool FAST>
+// QK8: the opt-in fp8 (e4m3, OCP) Q.K^T variant of BASELINE configs[4] ("fp8 MFMA attention QK", accuracy reported, not
+// gated): the K tile is converted to fp8 once while it is staged into LDS, Q once per block, and S^T = K.Q^T runs on
+// v_mfma_f32_32x32x16_fp8_fp8; softmax and P.V are unchanged (half operands).  On gfx950 the non-scaled fp8 MFMA has the
+// SAME rate as the f16 one (MI355X_MICROARCH.md: only the MX-scaled K = 128 forms double it, and d = 40 would pad them
+// to 31 % occupancy), so this buys LDS bytes, not MFMA time: it exists to measure the accuracy cost.
+typedef long i64_t;
+__device__ __forceinline__ i64_t half8_to_fp8(const uint4& v, int dt) {
+  float f[8];
+  if (dt == MIMO_F16) unpack8<MIMO_F16>(v, f);
+  else unpack8<MIMO_BF16>(v, f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return (i64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
+template <int DT, int D, bool FAST, bool QK8 = false>
 __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const AttnArgs a) {
   constexpr int KS = (D + 15) / 16;        // QK^T k-steps of 16
   constexpr int OT = (D + 31) / 32;        // 32-row tiles of O^T
@@ -47,7 +65,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
   constexpr int VP = KV_TILE + 4;          // V^T tile pitch (halfs): 8 * odd bytes
   constexpr int DC = D / 8;                // 16-byte chunks per head row
   constexpr int NBUF = D <= 80 ? 2 : 1;   // double-buffered K / V^T tiles where LDS and registers allow it
-  constexpr int KSZ = KV_TILE * KP, VSZ = OT * 32 * VP;
+  constexpr int KP8 = KS * 16 + 8;         // QK8: K tile pitch in BYTES (fp8), 8 * odd
+  constexpr int KSZ = QK8 ? (KV_TILE * KP8 + 1) / 2 : KV_TILE * KP, VSZ = OT * 32 * VP;
+  static_assert(!(QK8 && FAST), "the fp8 variant uses the plain online softmax");
   __shared__ __attribute__((aligned(16))) uint16_t Ks[NBUF * KSZ];
   __shared__ __attribute__((aligned(16))) uint16_t Vt[NBUF * VSZ];
 
@@ -88,6 +108,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
     }
   }
 
+  i64_t qf8[KS];
+  if (QK8) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf8[s] = half8_to_fp8(qf[s], DT);
+  }
   f32x16 ot[OT];
 #pragma unroll
   for (int t = 0; t < OT; ++t)
@@ -159,7 +184,13 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       if (live_[it]) {
-        *reinterpret_cast<uint4*>(&ks[klds_[it]]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
+        if (QK8) {  // 8 halfs -> 8 fp8 bytes at row * KP8 + 8 * chunk
+          const int kcc8 = (int)(klds_[it] - (unsigned)krow_[it] * KP) / 8;
+          *reinterpret_cast<i64_t*>(reinterpret_cast<unsigned char*>(ks) + krow_[it] * KP8 + kcc8 * 8) =
+              half8_to_fp8(make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w), DT);
+        } else {
+          *reinterpret_cast<uint4*>(&ks[klds_[it]]) = make_uint4(kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w);
+        }
         const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -204,8 +235,13 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(&ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
-        st[u] = HT<DT>::mfma32(kf, qf[s], s == 0 ? zero16 : st[u]);  // C = 0 folds into the instruction
+        if (QK8) {
+          const i64_t kf8 = *reinterpret_cast<const i64_t*>(reinterpret_cast<const unsigned char*>(ks) + (32 * u + li) * KP8 + 16 * s + 8 * h2);
+          st[u] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf8, qf8[s], s == 0 ? zero16 : st[u], 0, 0, 0);
+        } else {
+          const uint4 kf = *reinterpret_cast<const uint4*>(&ks[(32 * u + li) * KP + 16 * s + 8 * h2]);
+          st[u] = HT<DT>::mfma32(kf, qf[s], s == 0 ? zero16 : st[u]);  // C = 0 folds into the instruction
+        }
       }
     }
     // ---- online softmax over kv for this lane's query (raw-score max; scale folded into the exp2 fma) ----
@@ -1299,10 +1335,10 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((attn40_kernel<DT, 4, 0>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
-                              const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
-                              int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
-                              int seg2_first_batch, int heads, int d, float scale, void* stream) {
+static int attention_impl(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                          const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
+                          int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
+                          int seg2_first_batch, int heads, int d, float scale, void* stream, int qk8) {
   if (!q || !k || !v || !out || B <= 0 || Nq <= 0 || Nk <= 0 || heads <= 0) return MIMO_EINVAL;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return MIMO_EINVAL;
   if (Nk2 > 0 && (!k2 || !v2 || (ldk2 & 7) || (ldv2 & 7))) return MIMO_EINVAL;
@@ -1317,6 +1353,29 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
   a.prescaled = scale > 0.f ? 0 : 1;  // scale <= 0: Q is pre-multiplied by softmax_scale * log2(e)
   const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
+  if (qk8) {  // opt-in fp8 Q.K^T: the generic flash kernel with the K tile / Q fragments in e4m3
+#define ATTN_LAUNCH8(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD, false, true>), grid, dim3(256), 0, st, a)
+    if (dtype == MIMO_F16) {
+      switch (d) {
+        case 40: ATTN_LAUNCH8(MIMO_F16, 40); break;
+        case 80: ATTN_LAUNCH8(MIMO_F16, 80); break;
+        case 160: ATTN_LAUNCH8(MIMO_F16, 160); break;
+        default: return MIMO_EINVAL;
+      }
+    } else if (dtype == MIMO_BF16) {
+      switch (d) {
+        case 40: ATTN_LAUNCH8(MIMO_BF16, 40); break;
+        case 80: ATTN_LAUNCH8(MIMO_BF16, 80); break;
+        case 160: ATTN_LAUNCH8(MIMO_BF16, 160); break;
+        default: return MIMO_EINVAL;
+      }
+    } else {
+      return MIMO_EDTYPE;
+    }
+#undef ATTN_LAUNCH8
+    MIMO_LAUNCH_CHECK();
+    return MIMO_OK;
+  }
 #define ATTN_LAUNCH(DT, DD) hipLaunchKernelGGL((attn_kernel<DT, DD, false>), grid, dim3(256), 0, st, a)
   // d = 512: one head, no second segment, explicit scale (the VAE mid-block attention)
 #define ATTN_LAUNCH512(DT)                                                                         \
@@ -1357,6 +1416,22 @@ extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void*
 #undef ATTN_LAUNCH40
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
+}
+
+extern "C" int mimo_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                              const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
+                              int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
+                              int seg2_first_batch, int heads, int d, float scale, void* stream) {
+  return attention_impl(dtype, q, ldq, k, ldk, v, ldv, k2, ldk2, v2, ldv2, out, ldo, B, Nq, Nk, Nk2, seg2_first_batch, heads, d,
+                        scale, stream, 0);
+}
+
+extern "C" int mimo_attention_fp8qk(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                    const void* v, int64_t ldv, const void* k2, int64_t ldk2, const void* v2,
+                                    int64_t ldv2, void* out, int64_t ldo, int B, int Nq, int Nk, int Nk2,
+                                    int seg2_first_batch, int heads, int d, float scale, void* stream) {
+  return attention_impl(dtype, q, ldq, k, ldk, v, ldv, k2, ldk2, v2, ldv2, out, ldo, B, Nq, Nk, Nk2, seg2_first_batch, heads, d,
+                        scale, stream, 1);
 }
 
 extern "C" int mimo_temporal_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp],
     "mimo_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
+    "mimo_attention_fp8qk": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                       c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
     "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
     "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],

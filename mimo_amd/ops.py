@@ -386,6 +386,26 @@ def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=
     return out
 
 
+# Opt-in fp8 (e4m3) Q.K^T for the spatial attention (BASELINE configs[4]; accuracy reported, not gated).  `with
+# ops.fp8_qk(True): ...` routes every attention() call at d in {40, 80, 160} made inside the block to mimo_attention_fp8qk.
+_FP8_QK = False
+
+
+class fp8_qk:
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _FP8_QK
+        self.saved, _FP8_QK = _FP8_QK, self.enabled
+        return self
+
+    def __exit__(self, *a):
+        global _FP8_QK
+        _FP8_QK = self.saved
+        return False
+
+
 def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=None, q_prescaled=False):
     """Multi-head attention.  q: [B, Nq, C] view, k/v: [B, Nk, C] views (last stride 1, batch stride =
     N * row stride); optional shared second segment k2/v2: [Nk2, C] views for batches >= seg2_first_batch."""
@@ -409,7 +429,8 @@ def attention(q, k, v, heads, *, k2=None, v2=None, seg2_first_batch=0, scale=Non
     fl = 4 * Nq * C * (B * Nk + max(B - seg2_first_batch, 0) * Nk2)
     _count(fl)
     with _Bracket("attn_kernel", fl, (B * (Nq * 2 + Nk * 2) * C + (2 * Nk2 * C if Nk2 else 0)) * q.element_size()):
-        L.call("mimo_attention", dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
+        L.call("mimo_attention_fp8qk" if (_FP8_QK and d in (40, 80, 160)) else "mimo_attention",
+               dt_code(q.dtype), q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1),
                v.data_ptr(), v.stride(1), _ptr(k2), ldk2, _ptr(v2), ldv2, out.data_ptr(), C, B, Nq, Nk, Nk2,
                seg2_first_batch, heads, d, float(scale), _stream())
     return out

@@ -25,6 +25,54 @@ from .unet import ReferenceAttentionControl
 VAE_SCALE = 0.18215  # hard-coded by the reference pipeline (:115,431,439)
 
 
+# src/pipelines/utils.py: the interpolation used by interpolate_latents is a module-level choice that nothing in the
+# reference ever makes (set_tensor_interpolation_method is never called: interpolation_factor >= 2 raises TypeError there)
+tensor_interpolation = None
+
+
+def get_tensor_interpolation_method():
+    return tensor_interpolation
+
+
+def set_tensor_interpolation_method(is_slerp):
+    global tensor_interpolation
+    tensor_interpolation = slerp if is_slerp else linear
+
+
+def linear(v1, v2, t):
+    return (1.0 - t) * v1 + t * v2
+
+
+def slerp(v0, v1, t, DOT_THRESHOLD=0.9995):
+    u0, u1 = v0 / v0.norm(), v1 / v1.norm()
+    dot = (u0 * u1).sum()
+    if dot.abs() > DOT_THRESHOLD:
+        return (1.0 - t) * v0 + t * v1
+    omega = dot.acos()
+    return (((1.0 - t) * omega).sin() * v0 + (t * omega).sin() * v1) / omega.sin()
+
+
+def interpolate_latents(latents, interpolation_factor):
+    """pipeline_pose2vid_long_edit_bkfill_roiclip.py:293-336: (F - 1) * factor + 1 frames, the new ones interpolated between
+    neighbours with the method chosen by set_tensor_interpolation_method.  Off the hot path (factor 1 = the default =
+    identity); a handful of elementwise torch ops per inserted frame, on the device the latents live on."""
+    if interpolation_factor < 2:
+        return latents
+    fn = get_tensor_interpolation_method()
+    if fn is None:
+        raise TypeError("interpolation_factor >= 2 needs set_tensor_interpolation_method(is_slerp) first "
+                        "(src/pipelines/utils.py; the reference fails with 'NoneType is not callable' here)")
+    F = latents.shape[2]
+    rate = [i / interpolation_factor for i in range(interpolation_factor)][1:]
+    frames = []
+    for i0 in range(F - 1):
+        v0, v1 = latents[:, :, i0], latents[:, :, i0 + 1]
+        frames.append(v0)
+        frames += [fn(v0, v1, f) for f in rate]
+    frames.append(latents[:, :, F - 1])
+    return torch.stack(frames, dim=2).contiguous()
+
+
 class Pose2VideoPipelineOutput:
     def __init__(self, videos):
         self.videos = videos
@@ -366,8 +414,6 @@ class Pose2VideoPipeline:
         # that hit a cache entry published by another stream would read buffers it is not ordered behind
         self.prepack()
         steps_t = sched.timesteps.tolist()
-        # sinusoidal embeddings of all timesteps of the clip: one small table built on the host and uploaded once
-        temb_tab = unet.timestep_table(steps_t, 2 if guidance_scale > 1.0 else 1)
 
         ehs_c = clip_embeds.to(dev).float().reshape(1, 1, -1)
         ehs = torch.cat([torch.zeros_like(ehs_c), ehs_c], 0) if cfg else ehs_c
@@ -453,6 +499,9 @@ class Pose2VideoPipeline:
                 ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=win_x[wi][r_ * Fw:(r_ + 1) * Fw])
             return win_x[wi]
 
+        # time-embedding projections of ALL steps and the collapsed cross-attentions of the clip: four GEMMs per clip
+        # instead of four M = 2 launches per forward (they depend on (t, clip embedding) only)
+        temb_tab, attn2_tab = unet.clip_tables(steps_t, ehs, 2 if cfg else 1)
         units, my_units = plan_units(len(windows), cfg, rank, world)
         my_items = plan_items(len(windows), cfg, world)[rank] if world > 1 else []
         item_x, item_pose = [], []
@@ -467,11 +516,12 @@ class Pose2VideoPipeline:
         if world > 1:  # every window has the same frame count; the UNet's output head is padded to 4 channels
             cpad = (unet.out_channels + 3) // 4 * 4
             exch = UnitExchange(units, rank, world, (len(windows[0]), h, w, cpad), dev, self.dist_group)
+        gather_marks = []
         acc = torch.empty((2 if cfg else 1, C, F, h, w), device=dev, dtype=torch.float32)
         counter = torch.empty((F,), device=dev, dtype=torch.float32)
 
         for step, t in enumerate(steps_t):
-            te = temb_tab[step]
+            tk = dict(temb=temb_tab[step], attn2=attn2_tab)
             acc.zero_()
             counter.zero_()
             preds = {}
@@ -487,7 +537,7 @@ class Pose2VideoPipeline:
                 for wi, idx in enumerate(win_idx):
                     slot = wi % len(streams)
                     with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot):
-                        wpred.append(unet.run_tokens(fill_latents(wi), t, ehs, rep, idx.numel(), win_pose[wi], t_emb=te))
+                        wpred.append(unet.run_tokens(fill_latents(wi), t, ehs, rep, idx.numel(), win_pose[wi], **tk))
                 for s_ in streams:
                     main.wait_stream(s_)
                 for pred, idx in zip(wpred, win_idx):
@@ -502,7 +552,7 @@ class Pose2VideoPipeline:
                             self._graphs[key] = GraphedDenoiser(unet, rep, idx.numel(), h, w, pose_tok.shape[-1], dt)
                         pred = self._graphs[key](x, t, ehs, win_pose[wi])
                     else:
-                        pred = unet.run_tokens(x, t, ehs, rep, idx.numel(), win_pose[wi], t_emb=te)
+                        pred = unet.run_tokens(x, t, ehs, rep, idx.numel(), win_pose[wi], **tk)
                     ops.window_accumulate(pred, idx, acc, counter)
             else:
                 # a rank's items (whole windows as b = 2 forwards, single halves as b = 1 forwards) are independent:
@@ -534,19 +584,27 @@ class Pose2VideoPipeline:
                         for r_ in range(len(item)):
                             ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=x[r_ * Fw:(r_ + 1) * Fw])
                         if len(item) == 2:  # the whole window, batched exactly as on one GPU
-                            pred = unet.run_tokens(x, t, ehs, 2, Fw, item_pose[k], t_emb=te)
+                            pred = unet.run_tokens(x, t, ehs, 2, Fw, item_pose[k], **tk)
                             preds = [pred[:Fw], pred[Fw:]]
                         else:
                             half = item[0][1]
                             e = ehs[half:half + 1] if cfg else ehs
-                            preds = [self._run_unit(unet, x, t, e, Fw, item_pose[k], cond=(half == 1 or not cfg), t_emb=te[:1])]
+                            hk = dict(temb=tk["temb"][half:half + 1], attn2=attn2_tab[half:half + 1])  # this half's rows
+                            preds = [self._run_unit(unet, x, t, e, Fw, item_pose[k], cond=(half == 1 or not cfg), **hk)]
                     pending.append((preds, streams[slot]))
                     # the oldest pending item is handed over once every stream has a younger item queued behind it
                     if len(pending) == len(streams):
                         hand_over(pending.pop(0))
                 for entry in pending:
                     hand_over(entry)
+                if self.stage_times is not None:  # exposed part of the exchange: what the main stream waits for here
+                    g0 = torch.cuda.Event(enable_timing=True)
+                    g0.record()
                 allp = exch.finish()
+                if self.stage_times is not None:
+                    g1 = torch.cuda.Event(enable_timing=True)
+                    g1.record()
+                    gather_marks.append((g0, g1))
                 for wi, idx in enumerate(win_idx):  # canonical window order, uncond then cond: the single-GPU sums
                     for hf in ((0, 1) if cfg else (0,)):
                         ops.window_accumulate(allp[(wi, hf)], idx, acc[hf:hf + 1], counter if hf == 0 else counter_x)
@@ -571,9 +629,12 @@ class Pose2VideoPipeline:
             torch.cuda.synchronize()
             for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
                 self.stage_times[n1] = self.stage_times.get(n1, 0.0) + e0.elapsed_time(e1)
+            if gather_marks:
+                self.stage_times["exposed_gather_ms"] = self.stage_times.get("exposed_gather_ms", 0.0) + \
+                    sum(g0.elapsed_time(g1) for g0, g1 in gather_marks)
         return (video, latents) if return_latents else video
 
-    def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond, t_emb=None):
+    def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond, **tables):
         """One (window, CFG half) unit as a b = 1 forward.  The uncond half must not read the bank."""
         blocks = unet.spatial_blocks()
         saved = None
@@ -582,7 +643,7 @@ class Pose2VideoPipeline:
             for b in blocks:
                 b.bank_kv = None
         try:
-            return unet.run_tokens(x, t, ehs1, 1, Fw, pose, t_emb=t_emb)
+            return unet.run_tokens(x, t, ehs1, 1, Fw, pose, **tables)
         finally:
             if saved is not None:
                 for b, kv in zip(blocks, saved):
@@ -594,8 +655,13 @@ class Pose2VideoPipeline:
                  guidance_scale, num_images_per_prompt=1, eta=0.0, generator=None, output_type="tensor",
                  return_dict=True, callback=None, callback_steps=1, context_schedule="uniform", context_frames=24,
                  context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
-        if eta != 0.0 or context_batch_size != 1 or interpolation_factor != 1:
-            raise NotImplementedError("eta=0, context_batch_size=1, interpolation_factor=1 (the reference defaults) only")
+        if eta != 0.0:
+            raise NotImplementedError("eta = 0 (DDIM, the reference's setting) only")
+        if context_batch_size != 1:
+            # the reference itself cannot run this: with two windows per batch `encoder_hidden_states[:b]` has 2 rows for a
+            # batch of 4 and `noise_pred[:, :, c] + pred` (:540) adds a 4-row prediction to a 2-row accumulator
+            raise NotImplementedError("context_batch_size > 1 fails in the reference (shape mismatch at "
+                                      "pipeline_pose2vid_long_edit_bkfill_roiclip.py:524,540); windows run one per forward")
         dev = self.device
         from . import image as IM
         # CLIP image embedding (pipeline :379-384): `ref_image.resize((224, 224))` + CLIPImageProcessor run on the device
@@ -620,8 +686,13 @@ class Pose2VideoPipeline:
         cb = None
         if callback is not None:
             cb = lambda i, t, lat: callback(i, t, lat) if i % callback_steps == 0 else None
-        video = self.run_tensors(ref_t, bk_t, pose_t, clip_embeds, latents.float(), num_inference_steps, guidance_scale,
-                                 context_schedule, context_frames, context_stride, context_overlap, callback=cb)
+        if interpolation_factor >= 2:  # :566-567: decode the frame-interpolated latents
+            lat = self.run_tensors(ref_t, bk_t, pose_t, clip_embeds, latents.float(), num_inference_steps, guidance_scale,
+                                   context_schedule, context_frames, context_stride, context_overlap, callback=cb, decode=False)
+            video = self._decode_frames(interpolate_latents(lat, interpolation_factor))
+        else:
+            video = self.run_tensors(ref_t, bk_t, pose_t, clip_embeds, latents.float(), num_inference_steps, guidance_scale,
+                                     context_schedule, context_frames, context_stride, context_overlap, callback=cb)
         images = video.cpu().float()
         if output_type != "tensor":
             images = images.numpy()

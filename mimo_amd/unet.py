@@ -205,10 +205,28 @@ class UNetBase(HipModule):
         emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(self.compute_dtype)
         return emb[:, None, :].repeat(1, b, 1).contiguous().to(self.device)
 
+    def clip_tables(self, timesteps, ehs, b):
+        """Everything of a forward that depends only on (timestep, encoder_hidden_states), for ALL steps of a clip at once:
+        the time-embedding chain (Timesteps -> TimestepEmbedding -> SiLU -> the 22 stacked time_emb_proj, three GEMMs over
+        len(timesteps) * b rows instead of three M = 2 launches per forward) and the 16 collapsed cross-attentions (one
+        GEMM per clip: they do not depend on the step).  Returns (temb fp32 [S, b, sum(Cout)], attn2 fp32 [b, sum(C)]);
+        run_tokens(temb=..., attn2=...) then starts at conv_in.  The arithmetic per row is that of _time_and_cross."""
+        dt = self.compute_dtype
+        p = self.packed(dt)
+        S = len(timesteps)
+        t_emb = self.timestep_table(timesteps, b).view(S * b, -1)
+        e1 = ops.gemm(t_emb, p["t1_w"], bias=p["t1_b"], silu=True)
+        emb = ops.gemm(e1, p["t2_w"], bias=p["t2_b"], silu=True)
+        temb = ops.gemm(emb, p["temb_w"], bias=p["temb_b"], out_f32=True).view(S, b, -1)
+        e = ehs.reshape(b, -1).to(device=self.device, dtype=dt).contiguous()
+        return temb, ops.gemm(e, p["a2_w"], bias=p["a2_b"], out_f32=True)
+
     def _time_and_cross(self, ctx, p, timestep, ehs):
         """Timesteps(flip_sin_to_cos, shift 0) -> TimestepEmbedding -> silu -> ALL 22 time_emb_proj in one GEMM;
         ALL 16 collapsed cross-attentions in one GEMM (src/models/unet_3d_edit_bkfill.py:447-468, resnet.py:226)."""
         dev = self.device
+        if ctx.temb is not None and ctx.attn2 is not None:  # rows of clip_tables(): nothing left to do per forward
+            return
         if ctx.t_emb is not None:  # precomputed row of timestep_table()
             t_emb = ctx.t_emb
             assert t_emb.shape == (ctx.b, self.boc[0]) and t_emb.dtype == ctx.dtype and t_emb.is_contiguous()
@@ -225,13 +243,16 @@ class UNetBase(HipModule):
         e = ehs.reshape(ctx.b, -1).to(device=dev, dtype=ctx.dtype).contiguous()
         ctx.attn2 = ops.gemm(e, p["a2_w"], bias=p["a2_b"], out_f32=True)
 
-    def run_tokens(self, x_tok, timestep, ehs, b, F, pose_tok=None, ctx=None, t_emb=None):
+    def run_tokens(self, x_tok, timestep, ehs, b, F, pose_tok=None, ctx=None, t_emb=None, temb=None, attn2=None):
         """x_tok: half [b*F, h, w, Cin_pad8]; ehs: [b, 1, 768]; pose_tok: [b*F, h, w, C0] (fp32|half) or None.
         Returns fp32 tokens [b*F, h, w, Cout_pad4] (or the last hidden state when there is no output head)."""
         dt = self.compute_dtype
         p = self.packed(dt)
         ctx = ctx or Ctx(dt, b, F)
         ctx.t_emb = t_emb
+        if temb is not None and attn2 is not None:
+            assert temb.shape[0] == b and attn2.shape[0] == b and temb.stride(1) == 1 and attn2.stride(1) == 1
+            ctx.temb, ctx.attn2 = temb, attn2
         self._time_and_cross(ctx, p, timestep, ehs)
         n, H, W, _ = x_tok.shape
         up = 2 ** self.num_upsamplers

@@ -597,3 +597,26 @@ def test_template_functions_match_reference_tools_util():
     m = ns["clean_mask"](ns["extract_mask_sdc"](img))
     assert np.array_equal(T.clean_mask(T.extract_mask_sdc(img)), m)
     assert np.array_equal(T.crop_img(img, m), ns["crop_img"](img, m))
+
+
+@pytest.mark.reference
+def test_interpolate_latents_matches_reference():
+    """mimo_amd.pipeline.interpolate_latents == Pose2VideoPipeline.interpolate_latents (:293-336) with both methods of
+    src/pipelines/utils.py, run from the reference's own source."""
+    import sys
+    from oracle.diffusers_standin import install
+    install()
+    import src.pipelines.utils as RU
+    from src.pipelines.pipeline_pose2vid_long_edit_bkfill_roiclip import Pose2VideoPipeline as RefPipe
+    from mimo_amd import pipeline as P
+    lat = torch.randn(1, 4, 5, 6, 7, generator=torch.Generator().manual_seed(0))
+    for slerp in (False, True):
+        RU.set_tensor_interpolation_method(slerp)
+        P.set_tensor_interpolation_method(slerp)
+        for factor in (1, 2, 3):
+            ref = RefPipe.interpolate_latents(None, lat, factor, "cpu")
+            out = P.interpolate_latents(lat, factor)
+            assert out.shape == ref.shape and torch.allclose(out, ref, atol=1e-6, rtol=1e-6)
+    P.tensor_interpolation = None
+    with pytest.raises(TypeError):
+        P.interpolate_latents(lat, 2)

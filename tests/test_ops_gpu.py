@@ -399,6 +399,37 @@ def test_attention_single_head_d512(dev, dtype, N, B, spike):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,N,Nb", [(40, 256, 256), (40, 130, 70), (80, 100, 100), (160, 64, 0)])
+def test_attention_fp8_qk_variant(dev, dtype, d, N, Nb):
+    """mimo_attention_fp8qk (BASELINE configs[4], opt-in): Q.K^T on the e4m3 MFMA.  Pinned against a torch reference whose
+    Q and K are rounded to float8_e4m3fn first (then fp32 softmax / P.V): the kernel must reproduce THAT to the usual one
+    output rounding; the accuracy cost of the 8-bit operands against the 16-bit kernel is reported, not gated."""
+    from mimo_amd import ops
+    heads, B = 4, 4
+    C = heads * d
+    qkv = rnd((B, N, 3 * C), dev, dtype, 31)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    f8 = lambda t: t.float().to(torch.float8_e4m3fn).float()
+    kw = {}
+    if Nb:
+        bank = rnd((Nb, 2 * C), dev, dtype, 32)
+        kw = dict(k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=2)
+        ref_u = sdpa_ref(f8(q[:2]), f8(k[:2]), v[:2], heads)
+        kc = torch.cat([f8(k[2:]), f8(kw["k2"])[None].expand(2, -1, -1)], dim=1)
+        vc = torch.cat([v[2:].float(), kw["v2"].float()[None].expand(2, -1, -1)], dim=1)
+        ref = torch.cat([ref_u, sdpa_ref(f8(q[2:]), kc, vc, heads)], dim=0)
+    else:
+        ref = sdpa_ref(f8(q), f8(k), v, heads)
+    with ops.fp8_qk(True):
+        out = ops.attention(q, k, v, heads, **kw)
+    full = ops.attention(q, k, v, heads, **kw)
+    e8, cost = rel_l2(out.float(), ref), rel_l2(out.float(), full.float())
+    print(f"fp8 QK^T d={d} N={N}+{Nb} {dtype}: vs fp8-operand reference {e8:.2e}; accuracy cost vs the 16-bit kernel {cost:.2e}")
+    assert e8 < 2.5 * OUT_TOL[dtype]
+    assert 1e-4 < cost < 0.2  # it IS a different (coarser) computation, and not a broken one
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_forced_rescale(dev, dtype):
     """Spike a late key so the running max jumps in a later KV tile (online-softmax rescale path)."""
     from mimo_amd import ops

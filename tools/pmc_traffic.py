@@ -19,7 +19,7 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        fam = "gemm_kernel" if ("gemm_kernel" in k or "gemm_dense_persist_kernel" in k or "splitk_reduce" in k) else \
+        fam = "gemm_kernel" if ("gemm_kernel" in k or "gemm_dense_persist_kernel" in k or "gemm_stream_kernel" in k or "splitk_reduce" in k) else \
               "attn_kernel" if ("attn_kernel" in k or "attn40_kernel" in k) and "temporal" not in k else None
         if fam:
             tot[fam] += float(r["Counter_Value"])
@@ -40,6 +40,10 @@ def main():
                         note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/profile_forward.py; "
                              "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE as reported; fabric-side (MALL hits included)")
         out[fam]["traffic_bytes_per_launch"] = out[fam]["fetch_bytes_per_launch"] + out[fam]["write_bytes_per_launch"]
+    import hashlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimo_amd", "libmimo_hip.so")
+    out["library_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]  # the build the counters were taken on
     json.dump(out, sys.stdout, indent=1)
     print()
 
