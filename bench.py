@@ -262,7 +262,7 @@ def bf16_record(pipe, dev, inp, a, fp16_forward_out):
     return {"value": a.frames / el, "unit": "frames/s", "ms_per_step": el * 1e3, "steps": 1, "forward_rel_l2_vs_fp16": rel}
 
 
-def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16):
+def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16, fam_fp16):
     """BASELINE configs[4] names "fp8 MFMA attention QK" (accuracy reported, not gated): the same
     denoising forward with every spatial attention's Q.K^T on the e4m3 MFMA (mimo_attention_fp8qk, opt-in through
     ops.fp8_qk): rel-L2 of its output against the 16-bit forward of the same inputs, and its time.  The non-scaled fp8 MFMA
@@ -271,23 +271,13 @@ def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16):
     from mimo_amd import ops
     with ops.fp8_qk(True):
         out = forward_output(pipe, dev, dtype, size)
-        torch.cuda.synchronize()
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st.record()
-        for _ in range(2):
-            forward_output(pipe, dev, dtype, size)
-        en.record()
-        torch.cuda.synchronize()
+        t8, _, _, fam8 = measure_forward(pipe, dev, dtype, size)
     rel = float((out.float() - fp16_forward_out.float()).norm() / fp16_forward_out.float().norm())
-    st2, en2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st2.record()
-    for _ in range(2):
-        forward_output(pipe, dev, dtype, size)
-    en2.record()
-    torch.cuda.synchronize()
-    return {"forward_rel_l2_vs_16bit_qk": rel, "forward_ms_fp8_qk": st.elapsed_time(en) / 2,
-            "forward_ms_16bit_qk_same_harness": st2.elapsed_time(en2) / 2,
-            "note": "opt-in (ops.fp8_qk / mimo_attention_fp8qk); both timings include the reference-UNet bank set-up of the harness"}
+    att = lambda f: {"launches": f["attn_kernel"]["launches"], "ms_per_forward": round(f["attn_kernel"]["ms"], 3),
+                     "tflops": round(f["attn_kernel"]["flops"] / (f["attn_kernel"]["ms"] * 1e-3) / 1e12, 1)}
+    return {"forward_rel_l2_vs_16bit_qk": rel, "forward_ms_fp8_qk": t8 * 1e3, "forward_ms_16bit_qk": t_fwd_fp16 * 1e3,
+            "spatial_attention_fp8_qk": att(fam8), "spatial_attention_16bit_qk": att(fam_fp16),
+            "note": "opt-in (ops.fp8_qk / mimo_attention_fp8qk): Q.K^T on v_mfma_f32_32x32x16_fp8_fp8, softmax and P.V unchanged"}
 
 
 def forward_output(pipe, dev, dtype, size):
@@ -465,7 +455,7 @@ def main():
                 out["bf16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if a.fp8_qk and world == 1:
             try:
-                out["fp8_qk"] = fp8_qk_record(pipe, dev, dtype, a.size, forward_output(pipe, dev, dtype, a.size), t_fwd)
+                out["fp8_qk"] = fp8_qk_record(pipe, dev, dtype, a.size, forward_output(pipe, dev, dtype, a.size), t_fwd, fam)
             except Exception as e:
                 out["fp8_qk"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
