@@ -420,7 +420,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // each inside a busy phase) is fixed per block, so 8 waves halve its cost per FLOP.
 // STAGE: 0 = tiles by LDS-DMA (asm, counted vmcnt); 1 = tiles through registers: plain buffer loads issued at the top of the
 // iteration two tiles ahead, ds_write_b128 into the ring at its end (loads the compiler counts itself; NW = 4 only)
-template <int DT, int NW, int ABL = 0, int STAGE = 0>
+// PRIO: 0 = no priority hints; 1 = s_setprio(1) around both MFMA clusters of a tile (Q.K^T and P.V); 2 = around P.V only.
+// Two blocks share a CU, so each SIMD hosts two waves of DIFFERENT blocks whose phases drift: the hint lets the wave that
+// is entering an MFMA cluster win the issue arbitration against its partner's exp / pack VALU stream (cdna_hip_programming
+// T5; measured in profiles/r3_attn40_setprio_ab.txt).
+template <int DT, int NW, int ABL = 0, int STAGE = 0, int PRIO = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
   constexpr int NB = 3;                     // ring depth (tiles t, t+1, t+2)
@@ -705,8 +709,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     f32x16 sa[2], sb[2];
     uint32_t wa[2][8], wb[2][8];
     uint4 pa[2][2], pb[2][2];
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
     qk(kf, 0, sa);
     qk(kf, 1, sb);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     // V^T fragments of the whole tile: 12 transposed reads issued now, waited for after the softmax (the compiler does
     // not track asm loads: the wait statement below names every destination)
     uint2 vlo[3][2], vhi[3][2];
@@ -742,6 +748,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
                  :: "memory");
     __builtin_amdgcn_sched_barrier(0);  // no MFMA may be hoisted above the wait (cdna_hip_programming.md rule 18)
     // ---- O^T += V^T.P^T: d tiles {0..15, 16..31, 32..47}, two k-steps of 32 kv; every V^T fragment feeds 4 query tiles ----
+    if (PRIO != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -753,6 +760,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
           ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
         }
       }
+    if (PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if (t + 1 < T) {
       if (STAGE == 1) {
         if (t + 2 < T && ABL != 1) stage_write((CUR + 2) % NB);  // tile t+2: loaded at the top, readable after two barriers
@@ -1332,7 +1340,11 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
     return;
   }
 #endif
-  hipLaunchKernelGGL((attn40_kernel<DT, 4, 0>), grid, dim3(256), 0, st, a);
+  constexpr int PRIO_DEFAULT = 0;
+  const int prio = tune_env("MIMO_ATTN40_PRIO", PRIO_DEFAULT);
+  if (prio == 1) hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 1>), grid, dim3(256), 0, st, a);
+  else if (prio == 2) hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0>), grid, dim3(256), 0, st, a);
 }
 
 static int attention_impl(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,

@@ -278,16 +278,16 @@ def test_clip_image_encoder_vs_transformers(dev, dtype, size):
     assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
 
 
-def _sharded_clip_worker(rank, world, port, q):
+def _sharded_clip_worker(rank, world, port, q, F=26):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        q.put((rank, _small_clip(torch.device("cuda:0"), shard=True).cpu().numpy()))  # by value: the worker exits
+        q.put((rank, _small_clip(torch.device("cuda:0"), shard=True, F=F).cpu().numpy()))  # by value: the worker exits
     finally:
         dist.destroy_process_group()
 
 
-def _small_clip(dev, shard=False, invariant=False, window_streams=None):
+def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26):
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -295,8 +295,7 @@ def _small_clip(dev, shard=False, invariant=False, window_streams=None):
     _, _, p3, p2 = build_pair_unets(dtype, dev, seed=61)
     _, pv = build_pair_vae(dtype, dev, seed=62)
     _, pg = build_pair_pose(dtype, dev, seed=63)
-    H = W = 64
-    F = 26  # two wrapped 24-frame windows -> 4 (window, CFG-half) units
+    H = W = 64  # F = 26: two wrapped 24-frame windows -> 4 (window, CFG-half) units; F = 50: three windows; F = 24: one
     g = torch.Generator().manual_seed(7)
     ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
@@ -321,21 +320,30 @@ def test_window_streams_do_not_change_the_result(dev):
     assert torch.equal(one, two) and torch.equal(two, again)
 
 
-@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.skipif(
+@pytest.mark.parametrize("world,F", [(2, 26), (2, 24), (2, 50), pytest.param(4, 26, marks=pytest.mark.skipif(
     not os.environ.get("MIMO_TEST_WORLD4"), reason="four processes time-slicing one GPU take ~4 min; set MIMO_TEST_WORLD4=1 "
     "(passed on the MI355X box of round 2: profiles/r2_sharded_world4_one_gpu.txt)"))])
-def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world):
-    """one clip whose (window, CFG-half) units and per-frame stages are dealt over `world` ranks (all on this
-    GPU, collectives over gloo with host staging — RCCL refuses two ranks on one device) must reproduce the single-process
-    result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides).  F = 26 is two wrapped windows
-    = 4 (window, CFG-half) units: two per rank at world 2, one per rank at world 4."""
+def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F):
+    """one clip whose work items and per-frame stages are dealt over `world` ranks (all on this GPU,
+    collectives over gloo with host staging — RCCL refuses two ranks on one device) must reproduce the single-process
+    result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides).  The plan (pipeline.plan_items)
+    decides what a rank runs: F = 26 (two wrapped windows) on two ranks = one whole b = 2 window each; F = 24 (one window) =
+    its cond half on rank 0 and its uncond half on rank 1, as b = 1 forwards; F = 50 (three windows) = a whole window per
+    rank + the third window's two halves, one per rank (whole windows and single halves mixed on one rank, two exchange
+    slots); four ranks at F = 26 = one half each."""
     import torch.multiprocessing as mp
     import os
-    single = _small_clip(dev, invariant=True).cpu()
+    from mimo_amd.pipeline import plan_items
+    from mimo_amd.context import get_context_scheduler
+    nw = len(get_context_scheduler("uniform")(0, 2, F, 24, 1, 4))
+    kinds = sorted(len(it) for r in plan_items(nw, True, world) for it in r)
+    assert kinds == {(2, 26): [2, 2], (2, 24): [1, 1], (2, 50): [1, 1, 2, 2], (4, 26): [1, 1, 1, 1]}[(world, F)]
+    single = _small_clip(dev, invariant=True, F=F).cpu()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 400 + 11 + world
-    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, world, port, q)) for r in range(world)]
+    port += F
+    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, world, port, q, F)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = {r: torch.from_numpy(v) for r, v in (q.get(timeout=900) for _ in procs)}
@@ -343,7 +351,7 @@ def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world):
         p_.join(timeout=120)
     assert torch.isfinite(single).all()
     assert all(torch.equal(res[r], single) for r in range(world))
-    report(f"sharded long clip ({world} ranks, F = 26, 2 steps, fp16): latents and video bit-identical to the single-process run")
+    report(f"sharded long clip ({world} ranks, F = {F}, plan item sizes {kinds}, 2 steps, fp16): latents and video bit-identical to the single-process run")
 
 
 def test_pipeline_call_surface_pil_inputs(dev):

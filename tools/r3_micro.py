@@ -69,8 +69,32 @@ def vae_attn(dev, dt):
         print(f"     rel_l2(flash, unfused) = {float((a - bb).norm() / bb.norm()):.2e}")
 
 
+def attn40_prio(dev, dt):
+    """d = 40 spatial attention at the level-0 shapes (24 uncond images over N keys + 24 cond images over 2 N keys):
+    s_setprio hints around the MFMA clusters, interleaved A/B on random data; results must be bit-identical."""
+    print("attn40 s_setprio A/B (PRIO 0 none | 1 around Q.K^T and P.V | 2 around P.V only)")
+    for (N, nb) in [(4096, 48), (9216, 48)]:
+        C = 320
+        qkv = torch.randn(nb, N, 3 * C, device=dev).to(dt)
+        bank = torch.randn(N, 2 * C, device=dev).to(dt)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        fl = 4 * N * C * ((nb // 2) * N + (nb // 2) * 2 * N)
+        fn = lambda: ops.attention(q, k, v, 8, k2=bank[:, :C], v2=bank[:, C:], seg2_first_batch=nb // 2, q_prescaled=True)
+        best = {}
+        outs = {}
+        for rnd in range(3):
+            for prio in ("0", "1", "2"):
+                os.environ["MIMO_ATTN40_PRIO"] = prio
+                best[prio] = min(best.get(prio, 1e9), timeit(fn, iters=5, warm=1))
+                if rnd == 0:
+                    outs[prio] = fn().clone()
+        os.environ.pop("MIMO_ATTN40_PRIO", None)
+        same = all(torch.equal(outs["0"], outs[p_]) for p_ in ("1", "2"))
+        print(f"  N {N}: " + "  ".join(f"PRIO {p_}: {best[p_]:7.3f} ms ({fl/best[p_]/1e9:6.0f} TF/s)" for p_ in ("0", "1", "2")) + f"   bit-identical: {same}", flush=True)
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     what = sys.argv[1:] or ["temporal", "vae_attn"]
     for w in what:
-        {"temporal": temporal, "vae_attn": vae_attn}[w](dev, torch.float16)
+        {"temporal": temporal, "vae_attn": vae_attn, "attn40_prio": attn40_prio}[w](dev, torch.float16)
