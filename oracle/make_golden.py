@@ -9,6 +9,7 @@ Weights are NOT stored: tests rebuild them with oracle.synth.build (same seeds, 
   forward768  the same at BASELINE configs[4] shapes: 2 x 24 latent frames 96x96 (768x768; about 10 min, 30 GB)
   forward784  the scripts' DEFAULT size (run_animate.py:43-55: 784x784 -> latent 98x98, odd sizes 49 / 25 / 13 down the
               UNet, explicit-size upsampling on the way up): one denoising forward on 2 x 12 latent frames (about 6 min, 17 GB)
+  config784   FULL-SIZE models at the default 784x784: 8 frames, 4 DDIM steps, CFG 3.5 (VAE encodes + pose guider + both UNets)
   vae784      one frame of the VAE decoder at 784x784 (latent 98x98) with the oracle VAE (diffusers AutoencoderKL restatement)
   config1     FULL-SIZE models, BASELINE config 1: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 (latents after every step)
   config2     FULL-SIZE models, BASELINE config 2: 512x512, 24 frames, 20 DDIM steps, CFG 3.5 (latents after steps
@@ -140,6 +141,13 @@ def vae784():
 def config1():
     """BASELINE configs[0]: 256x256, 8 frames, 4 DDIM steps, CFG 3.5 through the reference's own models."""
     _clip(256, 8, 4, range(4), "config1_256_8f_4steps.safetensors")
+
+
+def config784():
+    """The scripts' default frame size (run_animate.py:43-55: 784x784) through the whole tensor path: VAE encode of the
+    reference image and of 8 background frames, pose guider, reference UNet, 4 DDIM steps with CFG on 98x98 latents (odd sizes
+    49 / 25 / 13 down the UNet); latents after every step (about 15 min on 8 cores)."""
+    _clip(784, 8, 4, range(4), "config784_8f_4steps.safetensors")
 
 
 def config2():
@@ -284,5 +292,5 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ["small"]
     for w in what:
-        {"small": small, "forward512": forward512, "forward768": forward768, "forward784": forward784, "vae784": vae784, "config1": config1, "config2": config2,
+        {"small": small, "forward512": forward512, "forward768": forward768, "forward784": forward784, "vae784": vae784, "config784": config784, "config1": config1, "config2": config2,
          "config2_video": config2_video, "multiwindow": multiwindow}[w]()

@@ -195,6 +195,39 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
 
 
 @pytest.mark.gpu
+def test_hip_config784_pipeline_vs_reference_golden(full_models):
+    """The scripts' DEFAULT frame size (run_animate.py:43-55: 784x784 -> 98x98 latents, odd sizes down the UNet) through the
+    whole tensor path with full-size models: VAE encode of the reference image and 8 background frames, pose guider,
+    reference UNet, 4 DDIM steps with CFG; latents after every step against the reference's own code on CPU fp32
+    (oracle/make_golden.py config784).  Same bars as configs[0]: 1e-3 on one forward, x 1.3 of the chained 4-step figure."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    G = gold("config784_8f_4steps.safetensors")
+    dev = torch.device("cuda:0")
+    H = W = 784
+    F = 8
+    g = torch.Generator().manual_seed(11)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.ones(F, 3, H, W)
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    m = full_models
+    pipe = Pose2VideoPipeline(m["vae"], None, m["ref"], m["den"], m["pose"], DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    traj = []
+    video = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 4, 3.5, trajectory=traj)
+    assert video.shape == (1, 3, F, H, W) and bool(torch.isfinite(video).all())
+    errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in range(4)]
+    e_ref = rel_l2(pipe._encode_frames(ref_img.to(dev)).permute(0, 3, 1, 2).float().cpu(), G["ref_latents"])
+    line = ("config 784x784 (8 f, 4 steps, full-size models) latents rel_l2 per step: " + " ".join("%.2e" % e for e in errs)
+            + f" | VAE-encoded reference latents {e_ref:.2e}")
+    print(line)
+    _report(line)
+    assert errs[0] < 1e-3 and errs[-1] < 1.5e-3 and e_ref < 2e-3
+
+
+@pytest.mark.gpu
 def test_hip_config2_pipeline_vs_reference_golden(full_models):
     """BASELINE configs[1] — the bench workload: 512x512, 24 frames, 20 DDIM steps, CFG 3.5, full-size models, VAE encode +
     pose guider + reference UNet + 20 denoising forwards, against the reference's own code on CPU fp32 (about 70 min
