@@ -237,6 +237,60 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     assert e_lat < {torch.float16: 1.85e-3, torch.bfloat16: 1.5e-2}[dtype]  # measured 1.41e-3 / 1.1e-2 (x 1.3)
 
 
+@pytest.mark.parametrize("F,guidance,hw", [(1, 3.5, 64), (5, 1.0, 64), (24, 1.0, 40), (3, 3.5, 104)])
+def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
+    """Edges of run_tensors against oracle.pipeline.run_clip: a ONE-frame clip (temporal attention over a single frame),
+    guidance 1.0 (no CFG: b = 1 forwards, banks read by every row, the no-CFG quirk of cfg_ddim), a full 24-frame window
+    without CFG on a 40x40 image (5x5 latents: every level below the 32-row MFMA tile), and a 104x104 image (13x13 latents:
+    odd sizes 13 / 7 / 4 / 2 through every down- and explicit-size up-sampler) — fp16."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    dtype = torch.float16
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=81)
+    ov, pv = build_pair_vae(dtype, dev, seed=82)
+    og, pg = build_pair_pose(dtype, dev, seed=83)
+    H = W = hw
+    g = torch.Generator().manual_seed(9)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        vid_o, lat_o = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), clip, ref_img, bk, pose, lat, 2, guidance)
+    pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    vid_p, lat_p = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, guidance, return_latents=True)
+    e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
+    report(f"pipeline edge F={F} guidance={guidance} {hw}x{hw} fp16: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
+    assert vid_p.shape == (1, 3, F, H, W) and bool(torch.isfinite(vid_p).all())
+    assert e_lat < 2.0e-3 and e_vid < 3.0e-3  # the half-width models' two-step figures (1.4e-3 / 1.0e-3 at F = 26) with headroom
+
+
+def test_pipeline_rejects_what_the_reference_cannot_run(dev):
+    """context windows longer than the motion modules' positional table (32) and context_batch_size > 1 fail loudly."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    dtype = torch.float16
+    _, _, p3, p2 = build_pair_unets(dtype, dev, seed=81)
+    _, pv = build_pair_vae(dtype, dev, seed=82)
+    _, pg = build_pair_pose(dtype, dev, seed=83)
+    pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    F, H = 40, 64
+    g = torch.Generator().manual_seed(1)
+    args = (torch.rand(1, 3, H, H, generator=g).to(dev) * 2 - 1, torch.rand(F, 3, H, H, generator=g).to(dev),
+            torch.rand(F, 3, H, H, generator=g).to(dev), torch.randn(1, 768, generator=g).to(dev),
+            torch.randn(1, 4, F, 8, 8, generator=g).to(dev), 1, 3.5)
+    with pytest.raises(ValueError, match="temporal_position_encoding_max_len"):
+        pipe.run_tensors(*args, context_frames=40)
+    from PIL import Image
+    im = Image.new("RGB", (64, 64))
+    with pytest.raises(NotImplementedError, match="context_batch_size"):
+        pipe(im, [im], [im], 64, 64, 1, 1, 3.5, context_batch_size=2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("size", ["small", "vit_l_14"])
 def test_clip_image_encoder_vs_transformers(dev, dtype, size):
@@ -287,7 +341,7 @@ def _sharded_clip_worker(rank, world, port, q, F=26):
         dist.destroy_process_group()
 
 
-def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26):
+def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0):
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -306,6 +360,8 @@ def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26):
     pipe.shard_windows, pipe.batch_invariant = shard, invariant
     if window_streams is not None:
         pipe.window_streams = window_streams
+    if delay_main_cycles:  # the main stream falls far behind the host: whatever a side stream needs from it must be ordered by events
+        torch.cuda._sleep(int(delay_main_cycles))
     vid, latents = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, 3.5, return_latents=True)
     return torch.cat([latents.flatten(), vid.flatten()])
 
@@ -318,6 +374,12 @@ def test_window_streams_do_not_change_the_result(dev):
     again = _small_clip(dev, window_streams=2)
     assert torch.isfinite(one).all()
     assert torch.equal(one, two) and torch.equal(two, again)
+    # Round-2 advisor finding: weights are packed lazily; a side stream must never consume packed buffers whose pack
+    # kernels sit on another stream.  Fresh (unpacked) models + a main stream stalled ~0.2 s behind the host: the pack
+    # kernels (issued on main by Pose2VideoPipeline.prepack before the fork) are still queued when the side streams'
+    # launches are issued — only the wait_stream(main) events keep the result right.
+    delayed = _small_clip(dev, window_streams=2, delay_main_cycles=4e8)
+    assert torch.equal(one, delayed)
 
 
 @pytest.mark.parametrize("world,F", [(2, 26), (2, 24), (2, 50), pytest.param(4, 26, marks=pytest.mark.skipif(
