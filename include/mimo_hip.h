@@ -189,6 +189,20 @@ int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C,
                     int pe_frames, void* out, float* out_f32, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * The GEGLU feed-forward of a transformer block in ONE launch (C = 320, the full-resolution level of the UNets):
+ *   out[M, C] (half16) = residual[M, C] (fp32) + GEGLU(A[M, C] @ W1^T + b1) @ W2^T + b2
+ *   replaces diffusers FeedForward([GEGLU(dim, 4 dim), Dropout, Linear(4 dim, dim)]) + the residual add of
+ *   src/models/attention.py:428-429 (spatial blocks, via mutual_self_attention.py:232-239) and
+ *   src/models/motion_module.py:258 (temporal blocks): the [M, 4C] GEGLU intermediate stays on the chip.
+ *   A: half16 LayerNorm output; W1: half16 [8C, C] GEGLU-packed as for mimo_gemm (16 value rows | 16 gate rows blocks),
+ *   b1 packed alike; W2: half16 [C, 4C] with its K axis permuted inside every 32-block (mimo_amd.packing.pack_ff2_kperm:
+ *   position 8g + j <- 4g + j | 16 + 4g + (j - 4)); b2 fp32 [C].  MIMO_EINVAL unless C == 320.
+ * --------------------------------------------------------------------------------- */
+int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
+                  const float* b2, const float* residual, int64_t ldr, void* out, int64_t ldo, int64_t M, int C,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional
  * second key/value segment shared by all batch rows b >= seg2_first_batch
  * (the reference-attention bank):

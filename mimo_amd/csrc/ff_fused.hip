@@ -1,0 +1,291 @@
+// ff_fused.hip — the GEGLU feed-forward of a transformer block as ONE kernel (gfx950), C = 320 (level 0 of the UNets):
+//
+//   out[M, C] = res[M, C] + GEGLU(A[M, C] @ W1^T + b1) @ W2^T + b2          (A = LayerNorm output, half; res fp32; out half)
+//
+// replaces diffusers FeedForward(GEGLU, Linear) + the residual add of src/models/attention.py:428-429 /
+// motion_module.py:258 as two launches (mimo_gemm GEGLU, then mimo_gemm + residual) with the [M, 4C] intermediate
+// (503 MB at 512x512x24f) written to and re-read from HBM.  Here the intermediate never leaves the chip: a block owns a
+// 128-row panel; per 32-column chunk of the hidden dimension it computes the chunk (FF1 + GEGLU) and immediately
+// multiplies it into the FF2 accumulators, which are initialised with the residual and stay in registers for the
+// whole panel.
+//
+// Block = 8 waves.  Waves w and w + 4 (the two waves of one SIMD) own the SAME 32 rows and split the columns:
+//   FF1: wave half s computes value/gate tile pair s of the 64-row W1 tile (16 hidden columns) -> 4 values per lane and row
+//        tile; the two halves swap their values lane-to-lane through 1 KB of LDS (every lane needs exactly what its twin
+//        lane in the partner wave holds: MFMA results have lanes along rows, 4 consecutive columns per lane),
+//   FF2: wave half s accumulates output columns [160 s, 160 s + 160) for its 32 rows (80 fp32 VGPRs).
+// The hidden chunk becomes the B operand of the FF2 MFMA straight from registers: the k order inside a 32-wide chunk is
+// whatever the accumulator layout gives (lane group g holds columns 4g..4g+3 and 16+4g..16+4g+3), and W2 is packed with
+// the same permutation of its K axis (mimo_amd.packing.pack_ff2_kperm), so no shuffle is needed.
+// W stream (as gemm_stream.hip): per step one 64 x 320 tile of W1 (40 KB) and one 320 x 32 slice of W2 (20 KB) by LDS-DMA
+// into 2-deep rings, swizzled on the source address; the stream is continuous across panels.
+// Pipeline: ONE barrier per step.  FF2 of chunk c runs in step c + 1 (its W2 slice is streamed one step behind the W1
+// tile, the partner's half of the chunk was written before the barrier).  Only the half-1 waves issue the DMAs, which
+// shifts them behind their SIMD partners: one wave's GELU (VALU) and DMA issue sit under the other's MFMAs.
+#include "common.cuh"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct FFArgs {
+  const uint16_t* A;    // half [M, lda], C columns
+  const uint16_t* W1;   // half [8C, C] GEGLU-packed (16 value rows | 16 gate rows blocks)
+  const uint16_t* W2;   // half [C, 4C], K axis permuted inside every 32-block (pack_ff2_kperm)
+  const float* b1;      // [8C] packed like W1
+  const float* b2;      // [C]
+  const float* res;     // fp32 [M, ldr]
+  uint16_t* out;        // half [M, ldo]
+  int64_t lda, ldr, ldo, M;
+};
+
+template <int V>
+struct ICf {
+  static constexpr int value = V;
+};
+
+constexpr int C = 320, KS = C / 32, HID = 4 * C, NSTEP = HID / 32;   // 40 steps per panel
+constexpr int ROWB1 = C * 2;                  // bytes of a W1 row
+constexpr int W1_TILE = 64 * ROWB1;           // 40 KB
+constexpr int W2_TILE = C * 64;               // 320 rows x 32 k x 2 B = 20 KB
+constexpr int STAGE = W1_TILE + W2_TILE;      // 60 KB
+constexpr int BIAS_OFF = 2 * STAGE;           // b1 (8C floats) then b2 (C floats)
+constexpr int XCH_OFF = BIAS_OFF + (8 * C + C) * 4;
+constexpr int LDS_BYTES = XCH_OFF + 2 * 8 * 1024;   // hidden-chunk exchange, double-buffered by step parity
+constexpr int BM = 128;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
+  __shared__ __attribute__((aligned(16))) uint4 smem[LDS_BYTES / 16];  // ONE LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned pr = wave_u & 3u, sh = wave_u >> 2;   // row group (32 rows) and column half
+  const int lg = lane >> 4, li = lane & 15;
+  const unsigned npanels = (unsigned)((g.M + BM - 1) / BM);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+  float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(&smem[0]) + BIAS_OFF);
+  for (int n = tid; n < 8 * C; n += 512) bias_lds[n] = g.b1 ? g.b1[n] : 0.f;
+  for (int n = tid; n < C; n += 512) bias_lds[8 * C + n] = g.b2 ? g.b2[n] : 0.f;
+
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(8 * C) * (unsigned)ROWB1);
+  const i32x4 rW2 = make_rsrc(g.W2, (unsigned)C * (unsigned)(HID * 2));
+  constexpr unsigned OOBA = 0x80000000u;
+
+  // ---- W stream.  Pieces of 1 KB per step: 0..39 = the W1 tile, 40..59 = the W2 slice; wave w moves pieces w, w + 8, ...
+  // W1 image: five K-blocks of [64 rows x 128 B]; chunk c of a row's 128-byte segment stored at c ^ (row & 7).
+  // W2 image: row n (output column) at n * 64 B, chunk q (8 permuted k) stored at q ^ (2 * ((n >> 3) & 1)): conflict-free
+  // for the ds_read_b128 lane groups (brute-forced against the grouping of MI355X_MICROARCH.md). ----
+  // Everything a lane contributes to a DMA address is loop-invariant (one VGPR per operand); the piece index and the
+  // stream position travel in the scalar offset:
+  //   W1 piece p = (K-block kb = p / 8, row group rg = p % 8): 8 rows x 128 B; lane l fetches row 8 rg + (l >> 3), logical
+  //   16-byte chunk (l & 7) ^ (row & 7) of the K-block -> byte (8 rg + (l >> 3)) * 640 + kb * 128 + chunk * 16 of the tile
+  //   W2 piece d: 16 rows x 64 B; lane l fetches row 16 d + (l >> 2), logical chunk (l & 3) ^ (2 * ((l >> 5) & 1))
+  const unsigned w1_lane = ((unsigned)lane >> 3) * (unsigned)ROWB1 + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 3) & 7u)) << 4);
+  const unsigned w2_lane = ((unsigned)lane >> 2) * (unsigned)(HID * 2) + ((((unsigned)lane & 3u) ^ (2u * (((unsigned)lane >> 5) & 1u))) << 4);
+  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(lds_dst) : "memory", "m0");
+  };
+  const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+  const unsigned total = my_panels * (unsigned)NSTEP;
+  unsigned ld_t = 0, ld_j = 0;
+  // issue(): the W1 tile of stream position ld_t (hidden chunk ld_j) into W1 stage ld_t & 1, and the W2 slice of position
+  // ld_t - 1 into W2 stage (ld_t - 1) & 1 (FF2 of a chunk runs one step after its FF1).  Only the waves of column half 1
+  // issue (15 pieces each): their ~1000 cycles of DMA issue shift them behind their SIMD partners of half 0, which start
+  // the step's MFMAs at once — the two waves of a SIMD then alternate between the matrix pipe and VALU / issue work
+  // with ONE code path (a second, reordered path for half 0 cost 15 scratch reloads per step at the 256-register cap).
+  auto issue_next = [&]() {
+    if (sh == 1u) {
+      const bool live1 = ld_t < total, live2 = ld_t >= 1u && ld_t <= total;
+      const unsigned dst1 = smem_base + (ld_t & 1u) * (unsigned)STAGE;
+      const unsigned dst2 = smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE;
+      const unsigned j2 = ld_j == 0u ? (unsigned)NSTEP - 1u : ld_j - 1u;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const unsigned p = pr + 4u * i, kb = p >> 3, rg = p & 7u;
+        dma(rW1, live1 ? w1_lane : OOBA, ld_j * (unsigned)W1_TILE + rg * (8u * ROWB1) + kb * 128u, dst1 + p * 1024u);
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const unsigned d = pr + 4u * i;
+        dma(rW2, live2 ? w2_lane : OOBA, j2 * 64u + d * (16u * HID * 2u), dst2 + d * 1024u);
+      }
+    }
+    ++ld_t;
+    ld_j = ld_j + 1 == (unsigned)NSTEP ? 0u : ld_j + 1;
+  };
+
+  // W1 fragment: tile row ni * 16 + li, logical chunk 4 ks + lg; this wave's tiles are ni = 2 sh (value), 2 sh + 1 (gate)
+  const unsigned bq0 = (unsigned)li * 8u + (unsigned)(lg ^ (li & 7));          // uint4 index inside a K-block, even k-steps
+  const unsigned bq1 = (unsigned)li * 8u + (unsigned)((4 + lg) ^ (li & 7));    // odd k-steps
+  // W2 fragment: row 160 sh + 16 nt + li, chunk lg ^ swizzle(li)
+  const unsigned w2q = (unsigned)(W1_TILE / 16) + (160u * sh + (unsigned)li) * 4u + (unsigned)(lg ^ (2 * ((li >> 3) & 1)));
+  const unsigned xch_mine = (unsigned)(XCH_OFF / 16) + (pr * 2u + sh) * 64u + (unsigned)lane;          // uint4 index into smem
+  const unsigned xch_peer = (unsigned)(XCH_OFF / 16) + (pr * 2u + (1u - sh)) * 64u + (unsigned)lane;
+  constexpr unsigned XCH_BUF = 8 * 1024 / 16;  // uint4 units between the two exchange buffers
+  constexpr unsigned BIAS_Q = BIAS_OFF / 16;   // uint4 index of the bias image (4 floats per uint4)
+
+  issue_next();     // W1 tile 0 (no W2 slice yet)
+  __syncthreads();  // bias image complete (the compiler drains its own loads; the DMAs are invisible to it)
+
+  unsigned t = 0;
+  for (unsigned panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
+    const int64_t M0 = (int64_t)panel * BM;
+    const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<uint16_t*>(g.A + M0 * g.lda), 0, (int)(((rows_valid - 1) * g.lda + C) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<float*>(g.res + M0 * g.ldr), 0, (int)(((rows_valid - 1) * g.ldr + C) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + C) * 2), 0x00020000);
+    // ---- this row group's 32 x 320 slice of A in MFMA operand layout (both column halves hold it) ----
+    uint4 fa[2][KS];
+    const unsigned a_off = (unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2);
+    const unsigned a_mi = (unsigned)(16 * g.lda * 2);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + mi * a_mi + ks * 64, 0, 0));
+    // ---- FF2 accumulators = residual + b2 for columns [160 sh, 160 sh + 160): lane (li, lg) owns 4 consecutive columns ----
+    f32x4 acc2[10][2];
+    const unsigned r_off = (unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 160 * sh + 4 * lg) * 4);
+    const unsigned r_mi = (unsigned)(16 * g.ldr * 4);
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) {
+      const f32x4 bv = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(2 * C) + 40u * sh + (unsigned)(4 * nt + lg)]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + mi * r_mi + nt * 64, 0, 0)) + bv;
+    }
+
+    u32x2 hm_prev[2] = {{0u, 0u}, {0u, 0u}};  // this wave's half of the previous chunk (packed), kept for its FF2
+    // FF1 + GEGLU of chunk j (stream position t): leaves this wave's half in hm_prev and in the exchange buffer t & 1
+    auto ff1 = [&](int j) {
+      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+      f32x4 acc1[2][2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc1[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      uint4 fb[KS][2];
+      auto ldb = [&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        const unsigned q = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);  // K-block = 64 rows x 128 B = 512 uint4
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[ks][ni] = smem[q + (2u * sh + (unsigned)ni) * 128u];  // 16 rows x 8 uint4
+      };
+      auto kstep = [&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if constexpr (ks + 1 < KS) ldb(ICf<ks + 1>{});
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc1[ni][mi] = HT<DT>::mfma16(fb[ks][ni], fa[mi][ks], acc1[ni][mi]);
+      };
+      ldb(ICf<0>{});
+      static_assert(KS == 10, "k-steps are spelled out");
+      kstep(ICf<0>{}); kstep(ICf<1>{}); kstep(ICf<2>{}); kstep(ICf<3>{}); kstep(ICf<4>{});
+      kstep(ICf<5>{}); kstep(ICf<6>{}); kstep(ICf<7>{}); kstep(ICf<8>{}); kstep(ICf<9>{});
+      // GEGLU: hidden columns 32 j + 16 sh + 4 lg + r of rows 16 mi + li
+      const f32x4 bval = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(16 * j) + 8u * sh + (unsigned)lg]);
+      const f32x4 bgate = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(16 * j) + 8u * sh + 4u + (unsigned)lg]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x4 v = acc1[0][mi] + bval, gt = acc1[1][mi] + bgate;
+        hm_prev[mi].x = pack2<DT>(v[0] * gelu_erf_f(gt[0]), v[1] * gelu_erf_f(gt[1]));
+        hm_prev[mi].y = pack2<DT>(v[2] * gelu_erf_f(gt[2]), v[3] * gelu_erf_f(gt[3]));
+      }
+      smem[xch_mine + (t & 1u) * XCH_BUF] = make_uint4(hm_prev[0].x, hm_prev[0].y, hm_prev[1].x, hm_prev[1].y);
+    };
+    // FF2 of the chunk whose stream position had parity `par`: this wave's half `hm`, the partner's from the exchange
+    // buffer `par`, the W2 slice in W2 stage `par`
+    auto ff2 = [&](unsigned par, const u32x2 (&hm)[2]) {
+      const uint4 pe = smem[xch_peer + par * XCH_BUF];
+      uint4 hf[2];  // B operand: k slots 0..3 = columns 4 lg + r of the chunk's first 16, 4..7 = of its second 16
+      if (sh == 0) {
+        hf[0] = make_uint4(hm[0].x, hm[0].y, pe.x, pe.y);
+        hf[1] = make_uint4(hm[1].x, hm[1].y, pe.z, pe.w);
+      } else {
+        hf[0] = make_uint4(pe.x, pe.y, hm[0].x, hm[0].y);
+        hf[1] = make_uint4(pe.z, pe.w, hm[1].x, hm[1].y);
+      }
+      const unsigned wq = par * (unsigned)(STAGE / 16) + w2q;
+#pragma unroll
+      for (int nt = 0; nt < 10; ++nt) {
+        const uint4 wf = smem[wq + (unsigned)nt * 64u];  // 16 rows x 64 B further
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc2[nt][mi] = HT<DT>::mfma16(wf, hf[mi], acc2[nt][mi]);
+      }
+    };
+
+    // first step of the panel: no FF2 yet
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_next();
+    ff1(0);
+    ++t;
+    // steady state: W1 tile t and W2 slice t - 1 have landed (every DMA a wave issued is older than its wait), the
+    // partner's half of chunk t - 1 is in the exchange buffer, every wave is done with the stages about to be refilled
+    for (int j = 1; j < NSTEP; ++j, ++t) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue_next();
+      ff2((t + 1u) & 1u, hm_prev);
+      __builtin_amdgcn_sched_barrier(0);  // FF1's fragment reads must not be hoisted into FF2 (register pressure)
+      ff1(j);
+    }
+    // drain: FF2 of the panel's last chunk (its W2 slice was issued in the last step)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ff2((t + 1u) & 1u, hm_prev);
+    // ---- epilogue: half output, 16-byte stores through the lane exchange of gemm_conv.hip's paired epilogue ----
+    const int row0 = (int)pr * 32 + li;
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) {
+      const f32x4 va = acc2[nt][0], vb = acc2[nt][1];
+      const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
+      const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+      // even 16-lane rows: row tile 0, columns 4 lg .. 4 lg + 7; odd rows: row tile 1, columns 4 (lg - 1) ..
+      const unsigned row = (unsigned)(row0 + (lg & 1) * 16);
+      const unsigned c8 = 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)(lg & ~1);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
+                             const float* b2, const float* residual, int64_t ldr, void* out, int64_t ldo, int64_t M,
+                             int C_, void* stream) {
+  if (!A || !W1 || !W2 || !residual || !out || M <= 0) return MIMO_EINVAL;
+  if (C_ != C) return MIMO_EINVAL;  // built for the 320-wide level (K = 320 operand in registers)
+  if ((lda & 7) || (ldr & 3) || (ldo & 7) || !aligned16(A) || !aligned16(W1) || !aligned16(W2) || !aligned16(residual) || !aligned16(out))
+    return MIMO_EINVAL;
+  if (((M - 1) * lda + C) * 2 >= 0x80000000LL || ((M - 1) * ldr + C) * 4 >= 0x100000000LL) return MIMO_EINVAL;
+  FFArgs g;
+  g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
+  g.out = (uint16_t*)out; g.lda = lda; g.ldr = ldr; g.ldo = ldo; g.M = M;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t npanels = (M + BM - 1) / BM;
+  const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIMO_F16) hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16>), dim3(grid), dim3(512), 0, st, g);
+  else if (dtype == MIMO_BF16) hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16>), dim3(grid), dim3(512), 0, st, g);
+  else return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import pack_conv, pack_geglu
+from .packing import pack_conv, pack_ff2_kperm, pack_geglu
 
 
 LOG2E = 1.4426950408889634
@@ -282,6 +282,12 @@ class _FeedForward(nn.Module):
 
 def _ff_run(ctx, p, x_f32, n3, out_f32):
     """(LN, already applied: n3) -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
+    # (batch-invariant runs — split-K off — take the fused kernel whatever the row count: a b = 1 unit and the b = 2 launch
+    # of the same window must go through the same kernel, the two forms differ in their fp32 summation order)
+    if ops.FF_FUSED and not out_f32 and p.get("ff2_wk") is not None and \
+            (n3.shape[0] >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled()):
+        # C = 320: FF1 + GEGLU + FF2 + residual in ONE launch, the [M, 4C] intermediate stays on the chip (ff_fused.hip)
+        return ops.ff_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], x_f32)
     h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
     return ops.gemm(h, p["ff2_w"], bias=p["ff2_b"], residual=x_f32, out_f32=out_f32)
 
@@ -313,6 +319,7 @@ class SpatialTransformerBlock(HipModule):
             kv=torch.cat([a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
             o_w=a1.to_out[0].weight.detach().to(dt).contiguous(), o_b=_f32(a1.to_out[0].bias),
             ff1_w=ff1_w, ff1_b=ff1_b, ff2_w=self.ff.net[2].weight.detach().to(dt).contiguous(),
+            ff2_wk=pack_ff2_kperm(self.ff.net[2].weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
             ff2_b=_f32(self.ff.net[2].bias),
             n1w=_f32(self.norm1.weight), n1b=_f32(self.norm1.bias),
             n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias))
@@ -460,6 +467,7 @@ class MotionModule(HipModule):
         d = dict(g=_f32(tt.norm.weight), b=_f32(tt.norm.bias), pi_w=h(tt.proj_in.weight), pi_b=_f32(tt.proj_in.bias),
                  po_w=h(tt.proj_out.weight), po_b=_f32(tt.proj_out.bias), ff1_w=ff1_w, ff1_b=ff1_b,
                  ff2_w=h(blk.ff.net[2].weight), ff2_b=_f32(blk.ff.net[2].bias),
+                 ff2_wk=pack_ff2_kperm(blk.ff.net[2].weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
                  fnw=_f32(blk.ff_norm.weight), fnb=_f32(blk.ff_norm.bias))
         for i, (a, nrm) in enumerate(zip(blk.attention_blocks, blk.norms)):
             d[f"qkv{i}"] = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous()

@@ -239,6 +239,30 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     return out, ln_out
 
 
+# The fused feed-forward kernel exists for the 320-wide level only (its K = 320 operand lives in registers).  Like every
+# kernel choice of this package the decision depends on the layer's width and on a fixed row threshold, never on how many
+# images share the launch beyond it (FF_FUSED_MIN_ROWS: below it the panel count cannot fill the chip).
+FF_FUSED = True
+FF_FUSED_DIM = 320
+FF_FUSED_MIN_ROWS = 8192
+
+
+def ff_fused(a, w1p, b1p, w2k, b2, residual):
+    """half [M, C] = residual (fp32) + GEGLU(a @ w1p^T + b1p) @ w2^T + b2 in ONE launch (C = 320): w1p / b1p GEGLU-packed
+    (packing.pack_geglu), w2k = packing.pack_ff2_kperm(net.2.weight).  The [M, 4C] intermediate never reaches HBM."""
+    _chk(a, "a")
+    M, C = a.shape
+    assert a.stride(1) == 1 and w1p.shape == (8 * C, C) and w2k.shape == (C, 4 * C) and w1p.is_contiguous() and w2k.is_contiguous()
+    assert residual.dtype == torch.float32 and residual.shape == (M, C) and residual.stride(1) == 1
+    out = torch.empty((M, C), device=a.device, dtype=a.dtype)
+    fl = 2 * M * C * (8 * C + 4 * C)
+    _count(fl)
+    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, residual, out)):
+        L.call("mimo_ff_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(), _ptr(b2),
+               residual.data_ptr(), residual.stride(0), out.data_ptr(), out.stride(0), M, C, _stream())
+    return out
+
+
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
            img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0, colstats=False,
            out=None):

@@ -41,3 +41,19 @@ def pack_geglu(weight, bias, dtype):
     b = bias.detach().float()
     bp = torch.stack([b[:inner].reshape(-1, 16), b[inner:].reshape(-1, 16)], dim=1).reshape(two_inner)
     return wp.to(dtype).contiguous(), bp.contiguous()
+
+
+def ff2_kperm():
+    """Position p = 8 g + j of a 32-wide K block holds original index 4 g + j (j < 4) | 16 + 4 g + (j - 4) (j >= 4): the order
+    in which the lanes of an MFMA result tile pair hold a 32-column chunk (lane group g: columns 4g..4g+3 of each 16-tile)."""
+    return [4 * (p // 8) + (p % 8) if (p % 8) < 4 else 16 + 4 * (p // 8) + (p % 8) - 4 for p in range(32)]
+
+
+def pack_ff2_kperm(weight, dtype):
+    """FeedForward net.2 Linear(4C, C) weight [C, 4C] for mimo_ff_fused: the K axis permuted inside every 32-block so that
+    the GEGLU chunk can feed the second MFMA straight from the first one's accumulator registers."""
+    co, k = weight.shape
+    assert k % 32 == 0
+    idx = torch.tensor(ff2_kperm(), device=weight.device)
+    w = weight.detach().float().reshape(co, k // 32, 32)[:, :, idx].reshape(co, k)
+    return w.to(dtype).contiguous()

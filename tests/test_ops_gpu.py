@@ -380,6 +380,38 @@ def test_attention_self_plus_bank(dev, dtype, d, N, Nb):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [128, 8192 + 77, 33, 40000])
+def test_ff_fused_c320(dev, dtype, M):
+    """mimo_ff_fused (C = 320): residual + GEGLU(a W1^T + b1) W2^T + b2 in one launch vs (i) a plain torch fp32 reference on
+    the same half-rounded operands with the hidden activations rounded to half where the kernel rounds them, and (ii) the
+    two-launch path it replaces (mimo_gemm GEGLU + mimo_gemm residual).  Ragged M (not a multiple of the 128-row panel), a
+    single partial panel, more panels than CUs."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_ff2_kperm, pack_geglu
+    C = 320
+    a = rnd((M, C), dev, dtype, 1)
+    w1 = rnd((8 * C, C), dev, torch.float32, 2, C ** -0.5)
+    b1 = rnd((8 * C,), dev, torch.float32, 3, 0.1)
+    w2 = rnd((C, 4 * C), dev, torch.float32, 4, (4 * C) ** -0.5)
+    b2 = rnd((C,), dev, torch.float32, 5, 0.1)
+    res = rnd((M, C), dev, torch.float32, 6)
+    w1p, b1p = pack_geglu(w1, b1, dtype)
+    w2k = pack_ff2_kperm(w2, dtype)
+    out = ops.ff_fused(a, w1p, b1p, w2k, b2, res)
+    assert out.shape == (M, C) and out.dtype == dtype
+    # reference on the rounded operands
+    w1r, w2r = w1.to(dtype).float(), w2.to(dtype).float()
+    hcat = a.float() @ w1r.t() + b1
+    hid = (hcat[:, :4 * C] * F.gelu(hcat[:, 4 * C:])).to(dtype).float()   # the kernel rounds the hidden chunk to half
+    ref = res + hid @ w2r.t() + b2
+    assert rel_l2(out.float(), ref) < OUT_TOL[dtype]
+    two = ops.gemm(ops.gemm(a, w1p, bias=b1p, geglu=True), w2.to(dtype).contiguous(), bias=b2, residual=res)
+    assert rel_l2(out.float(), two.float()) < OUT_TOL[dtype]
+    # asymmetric check of the row / column mapping: one row, one hidden unit
+    assert rel_l2(out[M // 2].float(), ref[M // 2]) < 2 * OUT_TOL[dtype] and rel_l2(out[:, 7].float(), ref[:, 7]) < 2 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,B,spike", [(64, 1, 0), (100, 3, 0), (1024, 2, 0), (333, 2, 5), (4096, 1, 0)])
 def test_attention_single_head_d512(dev, dtype, N, B, spike):
     """The VAE mid-block attention: ONE head of d = 512 over the N tokens of an image (attn512_kernel: head dimension split

@@ -1,0 +1,18 @@
+#!/bin/bash
+O=$PWD/gpurun_out/r3i; mkdir -p $O
+(timeout 900 python -m pytest tests/test_golden.py tests/test_models_gpu.py -m gpu -q -k "not sharded and not world" 2>&1 | tail -12) > $O/pytest.log
+(timeout 400 python bench.py --no-cpu-baseline --no-bf16 > $O/bench_fused.json 2> $O/bench.err)
+python - <<'PY' > $O/ab.txt 2>&1
+import sys, torch
+sys.path.insert(0, '.')
+import bench
+from mimo_amd import ops
+dev = torch.device("cuda:0")
+pipe = bench.build_pipeline(dev, torch.float16)
+for rnd in range(3):
+    for flag in (True, False):
+        ops.FF_FUSED = flag
+        t, fl, n, fam = bench.measure_forward(pipe, dev, torch.float16, 512, iters=5)
+        print(f"FF_FUSED={flag}: forward {t*1e3:.2f} ms, gemm family {fam['gemm_kernel']['ms']:.2f} ms over {fam['gemm_kernel']['launches']} launches", flush=True)
+PY
+tail -4 $O/pytest.log; cat $O/ab.txt; head -c 400 $O/bench_fused.json; grep -n "config-2\|full-size\|multi-window" gpurun_out/parity_report.txt | tail -6

@@ -69,6 +69,31 @@ def vae_attn(dev, dt):
         print(f"     rel_l2(flash, unfused) = {float((a - bb).norm() / bb.norm()):.2e}")
 
 
+def ff(dev, dt):
+    """Level-0 feed-forward (M = 196608, C = 320): the fused kernel vs the two launches it replaces, interleaved."""
+    from mimo_amd.packing import pack_ff2_kperm, pack_geglu
+    print("feed-forward C = 320: mimo_ff_fused vs mimo_gemm GEGLU + mimo_gemm residual")
+    C = 320
+    for M in (196608, 442368):
+        a = torch.randn(M, C, device=dev).to(dt)
+        w1 = torch.randn(8 * C, C, device=dev) * C ** -0.5
+        b1 = torch.randn(8 * C, device=dev) * 0.1
+        w2 = torch.randn(C, 4 * C, device=dev) * (4 * C) ** -0.5
+        b2 = torch.randn(C, device=dev) * 0.1
+        res = torch.randn(M, C, device=dev)
+        w1p, b1p = pack_geglu(w1, b1, dt)
+        w2k, w2h = pack_ff2_kperm(w2, dt), w2.to(dt).contiguous()
+        f1 = lambda: ops.ff_fused(a, w1p, b1p, w2k, b2, res)
+        f2 = lambda: ops.gemm(ops.gemm(a, w1p, bias=b1p, geglu=True), w2h, bias=b2, residual=res)
+        best = [1e9, 1e9]
+        for _ in range(3):
+            best[0] = min(best[0], timeit(f1, iters=10, warm=2))
+            best[1] = min(best[1], timeit(f2, iters=10, warm=2))
+        fl = 2 * M * C * 12 * C
+        d = float((f1().float() - f2().float()).norm() / f2().float().norm())
+        print(f"  M {M}: fused {best[0]:7.3f} ms ({fl/best[0]/1e9:6.0f} TF/s)   two launches {best[1]:7.3f} ms ({fl/best[1]/1e9:6.0f} TF/s)   rel_l2 {d:.2e}", flush=True)
+
+
 def attn40_prio(dev, dt):
     """d = 40 spatial attention at the level-0 shapes (24 uncond images over N keys + 24 cond images over 2 N keys):
     s_setprio hints around the MFMA clusters, interleaved A/B on random data; results must be bit-identical."""
@@ -97,4 +122,4 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     what = sys.argv[1:] or ["temporal", "vae_attn"]
     for w in what:
-        {"temporal": temporal, "vae_attn": vae_attn, "attn40_prio": attn40_prio}[w](dev, torch.float16)
+        {"temporal": temporal, "vae_attn": vae_attn, "attn40_prio": attn40_prio, "ff": ff}[w](dev, torch.float16)
