@@ -201,6 +201,13 @@ int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t rows, int C,
 int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
                   const float* b2, const float* residual, int64_t ldr, void* out, int64_t ldo, int64_t M, int C,
                   void* stream);
+/* The same with the block's output projection and its residual folded in (the end of Transformer3DModel.forward,
+ * src/models/transformer_3d.py:150-169, and of TemporalTransformer3DModel.forward, src/models/motion_module.py:170-184):
+ *   out[M, C] (fp32) = x[M, C] (fp32, the block input) + (residual + FF(A)) @ Wp^T + bp
+ *   Wp: half16 [C, C] = proj_out.weight with rows in tile order and the K axis permuted (mimo_amd.packing.pack_proj_tail). */
+int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
+                       const float* b2, const float* residual, int64_t ldr, const void* Wp, const float* bp,
+                       const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional

@@ -38,8 +38,14 @@ struct FFArgs {
   const float* b1;      // [8C] packed like W1
   const float* b2;      // [C]
   const float* res;     // fp32 [M, ldr]
-  uint16_t* out;        // half [M, ldo]
+  uint16_t* out;        // half [M, ldo]                                         (TAIL = 0)
   int64_t lda, ldr, ldo, M;
+  // TAIL = 1: the block's output projection folded in:  out32 = x + (res + FF(A)) @ Wp^T + bp
+  const uint16_t* Wp;   // half [C, C]: rows in tile order (tile q = columns 32q..32q+31 | 160+32q..160+32q+31), K axis permuted
+  const float* bp;      // [C]
+  const float* x;       // fp32 [M, ldx]: the block input (the residual of proj_out)
+  float* out32;         // fp32 [M, ldo32]
+  int64_t ldx, ldo32;
 };
 
 template <int V>
@@ -52,14 +58,16 @@ constexpr int ROWB1 = C * 2;                  // bytes of a W1 row
 constexpr int W1_TILE = 64 * ROWB1;           // 40 KB
 constexpr int W2_TILE = C * 64;               // 320 rows x 32 k x 2 B = 20 KB
 constexpr int STAGE = W1_TILE + W2_TILE;      // 60 KB
-constexpr int BIAS_OFF = 2 * STAGE;           // b1 (8C floats) then b2 (C floats)
-constexpr int XCH_OFF = BIAS_OFF + (8 * C + C) * 4;
+constexpr int BIAS_OFF = 2 * STAGE;           // b1 (8C floats), b2 (C floats), bp (C floats)
+constexpr int XCH_OFF = BIAS_OFF + (8 * C + 2 * C) * 4;
+constexpr int NTAIL = C / 64;                 // W tiles of the folded output projection
 constexpr int LDS_BYTES = XCH_OFF + 2 * 8 * 1024;   // hidden-chunk exchange, double-buffered by step parity
 constexpr int BM = 128;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
-template <int DT>
+template <int DT, int TAIL>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
+  constexpr int NPOS = NSTEP + (TAIL ? NTAIL : 0);   // stream positions (W tiles of the W1 region) per panel
   __shared__ __attribute__((aligned(16))) uint4 smem[LDS_BYTES / 16];  // ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,6 +78,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(&smem[0]) + BIAS_OFF);
   for (int n = tid; n < 8 * C; n += 512) bias_lds[n] = g.b1 ? g.b1[n] : 0.f;
   for (int n = tid; n < C; n += 512) bias_lds[8 * C + n] = g.b2 ? g.b2[n] : 0.f;
+  for (int n = tid; n < C; n += 512) bias_lds[9 * C + n] = (TAIL && g.bp) ? g.bp[n] : 0.f;
 
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   };
   const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(8 * C) * (unsigned)ROWB1);
   const i32x4 rW2 = make_rsrc(g.W2, (unsigned)C * (unsigned)(HID * 2));
+  const i32x4 rWp = make_rsrc(TAIL ? g.Wp : g.W1, TAIL ? (unsigned)C * (unsigned)ROWB1 : 0u);
   constexpr unsigned OOBA = 0x80000000u;
 
   // ---- W stream.  Pieces of 1 KB per step: 0..39 = the W1 tile, 40..59 = the W2 slice; wave w moves pieces w, w + 8, ...
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
                  :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(lds_dst) : "memory", "m0");
   };
   const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
-  const unsigned total = my_panels * (unsigned)NSTEP;
+  const unsigned total = my_panels * (unsigned)NPOS;
   unsigned ld_t = 0, ld_j = 0;
   // issue(): the W1 tile of stream position ld_t (hidden chunk ld_j) into W1 stage ld_t & 1, and the W2 slice of position
   // ld_t - 1 into W2 stage (ld_t - 1) & 1 (FF2 of a chunk runs one step after its FF1).  Only the waves of column half 1
@@ -106,23 +116,29 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   // with ONE code path (a second, reordered path for half 0 cost 15 scratch reloads per step at the 256-register cap).
   auto issue_next = [&]() {
     if (sh == 1u) {
-      const bool live1 = ld_t < total, live2 = ld_t >= 1u && ld_t <= total;
+      const bool live1 = ld_t < total;
+      const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;      // position ld_t - 1 inside its panel
+      const bool live2 = ld_t >= 1u && ld_t <= total && j2 < (unsigned)NSTEP;  // (the projection tiles have no W2 slice)
       const unsigned dst1 = smem_base + (ld_t & 1u) * (unsigned)STAGE;
       const unsigned dst2 = smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE;
-      const unsigned j2 = ld_j == 0u ? (unsigned)NSTEP - 1u : ld_j - 1u;
+      const bool tail_tile = TAIL && ld_j >= (unsigned)NSTEP;
+      const i32x4 r1 = tail_tile ? rWp : rW1;
+      const unsigned tile = tail_tile ? ld_j - (unsigned)NSTEP : ld_j;
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
         const unsigned p = pr + 4u * i, kb = p >> 3, rg = p & 7u;
-        dma(rW1, live1 ? w1_lane : OOBA, ld_j * (unsigned)W1_TILE + rg * (8u * ROWB1) + kb * 128u, dst1 + p * 1024u);
+        dma(r1, live1 ? w1_lane : OOBA, tile * (unsigned)W1_TILE + rg * (8u * ROWB1) + kb * 128u, dst1 + p * 1024u);
       }
+      if (live2) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const unsigned d = pr + 4u * i;
-        dma(rW2, live2 ? w2_lane : OOBA, j2 * 64u + d * (16u * HID * 2u), dst2 + d * 1024u);
+        for (int i = 0; i < 5; ++i) {
+          const unsigned d = pr + 4u * i;
+          dma(rW2, w2_lane, j2 * 64u + d * (16u * HID * 2u), dst2 + d * 1024u);
+        }
       }
     }
     ++ld_t;
-    ld_j = ld_j + 1 == (unsigned)NSTEP ? 0u : ld_j + 1;
+    ld_j = ld_j + 1 == (unsigned)NPOS ? 0u : ld_j + 1;
   };
 
   // W1 fragment: tile row ni * 16 + li, logical chunk 4 ks + lg; this wave's tiles are ni = 2 sh (value), 2 sh + 1 (gate)
@@ -245,19 +261,91 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     }
     // drain: FF2 of the panel's last chunk (its W2 slice was issued in the last step)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (TAIL) issue_next();  // second projection tile (the first one was issued in the last FF step and has landed)
     ff2((t + 1u) & 1u, hm_prev);
-    // ---- epilogue: half output, 16-byte stores through the lane exchange of gemm_conv.hip's paired epilogue ----
     const int row0 = (int)pr * 32 + li;
+    if constexpr (!TAIL) {
+      // ---- epilogue: half output, 16-byte stores through the lane exchange of gemm_conv.hip's paired epilogue ----
 #pragma unroll
-    for (int nt = 0; nt < 10; ++nt) {
-      const f32x4 va = acc2[nt][0], vb = acc2[nt][1];
-      const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
-      const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
-      const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
-      // even 16-lane rows: row tile 0, columns 4 lg .. 4 lg + 7; odd rows: row tile 1, columns 4 (lg - 1) ..
-      const unsigned row = (unsigned)(row0 + (lg & 1) * 16);
-      const unsigned c8 = 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)(lg & ~1);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, 0);
+      for (int nt = 0; nt < 10; ++nt) {
+        const f32x4 va = acc2[nt][0], vb = acc2[nt][1];
+        const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
+        const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+        // even 16-lane rows: row tile 0, columns 4 lg .. 4 lg + 7; odd rows: row tile 1, columns 4 (lg - 1) ..
+        const unsigned row = (unsigned)(row0 + (lg & 1) * 16);
+        const unsigned c8 = 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)(lg & ~1);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, 0);
+      }
+    } else {
+      // ---- the block's output projection: out32 = x + z @ Wp^T + bp, z = the FF result just accumulated (fp32, this wave:
+      // columns [160 sh, 160 sh + 160)).  z becomes the MFMA operand straight from the accumulators (k order inside a
+      // 32-block = the accumulator layout; Wp is packed with the same permutation); the partner's 5 k-steps come through
+      // the exchange buffers, one k-step per round. ----
+      const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(g.out32 + M0 * g.ldo32), 0, (int)(((rows_valid - 1) * g.ldo32 + C) * 4), 0x00020000);
+      auto zop = [&](int kk, int mi) -> uint4 {  // k-step kk (0..4) of this wave's own columns
+        const f32x4 a0 = acc2[2 * kk][mi], a1 = acc2[2 * kk + 1][mi];
+        return make_uint4(pack2<DT>(a0[0], a0[1]), pack2<DT>(a0[2], a0[3]), pack2<DT>(a1[0], a1[1]), pack2<DT>(a1[2], a1[3]));
+      };
+      // (the partner may still be reading this wave's half of the last chunk: no exchange buffer is rewritten before everyone
+      // is through its drain)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const uint4 m0 = zop(kk, 0), m1 = zop(kk, 1);
+        smem[xch_mine] = m0;
+        smem[xch_mine + XCH_BUF] = m1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const uint4 p0 = smem[xch_peer], p1 = smem[xch_peer + XCH_BUF];
+        if (sh == 0) {
+          fa[0][kk] = m0; fa[1][kk] = m1; fa[0][5 + kk] = p0; fa[1][5 + kk] = p1;
+        } else {
+          fa[0][kk] = p0; fa[1][kk] = p1; fa[0][5 + kk] = m0; fa[1][5 + kk] = m1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // both halves have read before the next round writes
+      }
+      // accumulators re-initialised with the block input + bias
+      const unsigned x_off = (unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 160 * sh + 4 * lg) * 4);
+      const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
+#pragma unroll
+      for (int nt = 0; nt < 10; ++nt) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(9 * C / 4) + 40u * sh + (unsigned)(4 * nt + lg)]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + mi * x_mi + nt * 64, 0, 0)) + bv;
+      }
+      // five tiles of Wp: tile q holds this wave's output columns 32 q .. 32 q + 31 (of its 160) as its n-tiles 2 sh, 2 sh + 1
+      auto proj = [&](auto q_c) {
+        constexpr int q = decltype(q_c)::value;
+        const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc2[2 * q + ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], acc2[2 * q + ni][mi]);
+          }
+        }
+      };
+      // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, issue the next, multiply
+      proj(ICf<0>{});
+      ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t;
+      static_assert(NTAIL == 5, "projection tiles are spelled out");
+#pragma unroll
+      for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
+                                                 ((unsigned)(row0 + 16 * mi) * (unsigned)g.ldo32 + 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)lg) * 4u, 0, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
@@ -267,6 +355,25 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+static int ff_launch(int dtype, FFArgs& g, bool tail, void* stream) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t npanels = (g.M + BM - 1) / BM;
+  const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIMO_F16) {
+    if (tail) hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16, 1>), dim3(grid), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16, 0>), dim3(grid), dim3(512), 0, st, g);
+  } else if (dtype == MIMO_BF16) {
+    if (tail) hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16, 1>), dim3(grid), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16, 0>), dim3(grid), dim3(512), 0, st, g);
+  } else {
+    return MIMO_EDTYPE;
+  }
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
 extern "C" int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
                              const float* b2, const float* residual, int64_t ldr, void* out, int64_t ldo, int64_t M,
                              int C_, void* stream) {
@@ -275,17 +382,26 @@ extern "C" int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* 
   if ((lda & 7) || (ldr & 3) || (ldo & 7) || !aligned16(A) || !aligned16(W1) || !aligned16(W2) || !aligned16(residual) || !aligned16(out))
     return MIMO_EINVAL;
   if (((M - 1) * lda + C) * 2 >= 0x80000000LL || ((M - 1) * ldr + C) * 4 >= 0x100000000LL) return MIMO_EINVAL;
-  FFArgs g;
+  FFArgs g{};
   g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
   g.out = (uint16_t*)out; g.lda = lda; g.ldr = ldr; g.ldo = ldo; g.M = M;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const int64_t npanels = (M + BM - 1) / BM;
-  const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIMO_F16) hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16>), dim3(grid), dim3(512), 0, st, g);
-  else if (dtype == MIMO_BF16) hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16>), dim3(grid), dim3(512), 0, st, g);
-  else return MIMO_EDTYPE;
-  MIMO_LAUNCH_CHECK();
-  return MIMO_OK;
+  return ff_launch(dtype, g, false, stream);
+}
+
+extern "C" int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
+                                  const float* b2, const float* residual, int64_t ldr, const void* Wp, const float* bp,
+                                  const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C_, void* stream) {
+  if (!A || !W1 || !W2 || !residual || !Wp || !x || !out || M <= 0) return MIMO_EINVAL;
+  if (C_ != C) return MIMO_EINVAL;
+  if ((lda & 7) || (ldr & 3) || (ldx & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W1) || !aligned16(W2) || !aligned16(residual) ||
+      !aligned16(Wp) || !aligned16(x) || !aligned16(out))
+    return MIMO_EINVAL;
+  if (((M - 1) * lda + C) * 2 >= 0x80000000LL || ((M - 1) * ldr + C) * 4 >= 0x100000000LL || ((M - 1) * ldx + C) * 4 >= 0x100000000LL ||
+      ((M - 1) * ldo + C) * 4 >= 0x100000000LL)
+    return MIMO_EINVAL;
+  FFArgs g{};
+  g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
+  g.lda = lda; g.ldr = ldr; g.M = M;
+  g.Wp = (const uint16_t*)Wp; g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo;
+  return ff_launch(dtype, g, true, stream);
 }

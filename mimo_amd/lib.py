@@ -57,6 +57,7 @@ SIGNATURES = {
     "mimo_attention_fp8qk": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
     "mimo_ff_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
+    "mimo_ff_proj_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
     "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
     "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import pack_conv, pack_ff2_kperm, pack_geglu
+from .packing import pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
 
 
 LOG2E = 1.4426950408889634
@@ -280,16 +280,29 @@ class _FeedForward(nn.Module):
         self.net = nn.ModuleList([_GEGLU(dim, 4 * dim), nn.Identity(), nn.Linear(4 * dim, dim)])
 
 
-def _ff_run(ctx, p, x_f32, n3, out_f32):
-    """(LN, already applied: n3) -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
+def _ff_fusable(p, n3, out_f32):
     # (batch-invariant runs — split-K off — take the fused kernel whatever the row count: a b = 1 unit and the b = 2 launch
     # of the same window must go through the same kernel, the two forms differ in their fp32 summation order)
-    if ops.FF_FUSED and not out_f32 and p.get("ff2_wk") is not None and \
-            (n3.shape[0] >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled()):
+    return ops.FF_FUSED and not out_f32 and p.get("ff2_wk") is not None and \
+        (n3.shape[0] >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled())
+
+
+def _ff_run(ctx, p, x_f32, n3, out_f32):
+    """(LN, already applied: n3) -> GEGLU GEMM -> GEMM + residual.  Returns fp32 (residual stream) or half (feeds a projection)."""
+    if _ff_fusable(p, n3, out_f32):
         # C = 320: FF1 + GEGLU + FF2 + residual in ONE launch, the [M, 4C] intermediate stays on the chip (ff_fused.hip)
         return ops.ff_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], x_f32)
     h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
     return ops.gemm(h, p["ff2_w"], bias=p["ff2_b"], residual=x_f32, out_f32=out_f32)
+
+
+def _ff_proj_run(ctx, p, y_f32, n3, proj, x_f32, colstats):
+    """Feed-forward + the block's output projection + its residual: x + proj_out(y + FF(n3)).  proj = dict(po_w, po_b,
+    po_wk) of the owning module.  One launch where the fused kernel applies (C = 320), three otherwise."""
+    if ops.FF_PROJ_FUSED and proj.get("po_wk") is not None and _ff_fusable(p, n3, False):
+        return ops.ff_proj_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], y_f32, proj["po_wk"], proj["po_b"], x_f32)
+    z = _ff_run(ctx, p, y_f32, n3, out_f32=False)
+    return ops.gemm(z, proj["po_w"], bias=proj["po_b"], residual=x_f32, out_f32=True, colstats=colstats)
 
 
 class SpatialTransformerBlock(HipModule):
@@ -338,9 +351,10 @@ class SpatialTransformerBlock(HipModule):
         p = self.packed(dtype)
         return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps)
 
-    def run(self, ctx, t, n_img, N, out_f32=False, n1=None):
+    def run(self, ctx, t, n_img, N, out_f32=False, n1=None, proj=None, x=None):
         """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it.
-        Returns the block output (half unless out_f32)."""
+        Returns the block output (half unless out_f32) — or, with proj = the owning transformer's packed proj_out and
+        x = its fp32 input tokens, the transformer's output x + proj_out(block output) (fp32)."""
         p = self.packed(ctx.dtype)
         C = self.dim
         if n1 is None:
@@ -364,6 +378,8 @@ class SpatialTransformerBlock(HipModule):
         y, n3 = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
                          rows_per_img=ctx.F * N, residual=t, out_f32=True,
                          ln=dict(gamma=p["n3w"], beta=p["n3b"], eps=self.norm3.eps))
+        if proj is not None:
+            return _ff_proj_run(ctx, p, y, n3, proj, x, N)
         return _ff_run(ctx, p, y, n3, out_f32)
 
     def set_bank(self, bank, dtype):
@@ -396,7 +412,9 @@ class SpatialTransformer(HipModule):
         return dict(g=_f32(self.norm.weight), b=_f32(self.norm.bias),
                     pi_w=self.proj_in.weight.detach().reshape(C, -1).to(dt).contiguous(), pi_b=_f32(self.proj_in.bias),
                     po_w=self.proj_out.weight.detach().reshape(self.proj_out.out_channels, -1).to(dt).contiguous(),
-                    po_b=_f32(self.proj_out.bias))
+                    po_b=_f32(self.proj_out.bias),
+                    po_wk=pack_proj_tail(self.proj_out.weight.detach().reshape(self.proj_out.out_channels, -1), dt)
+                    if C == ops.FF_FUSED_DIM and self.proj_out.out_channels == C else None)
 
     def run(self, ctx, x):
         p = self.packed(ctx.dtype)
@@ -404,8 +422,7 @@ class SpatialTransformer(HipModule):
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=1e-6, silu=False, dtype=ctx.dtype)
         blk = self.transformer_blocks[0]
         t, n1 = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=blk.ln1(ctx.dtype))
-        z = blk.run(ctx, t, n, H * W, n1=n1)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=H * W)
+        out = blk.run(ctx, t, n, H * W, n1=n1, proj=p, x=x.view(-1, C))  # ... + proj_out + residual (one launch at C = 320)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
 
 
@@ -468,6 +485,7 @@ class MotionModule(HipModule):
                  po_w=h(tt.proj_out.weight), po_b=_f32(tt.proj_out.bias), ff1_w=ff1_w, ff1_b=ff1_b,
                  ff2_w=h(blk.ff.net[2].weight), ff2_b=_f32(blk.ff.net[2].bias),
                  ff2_wk=pack_ff2_kperm(blk.ff.net[2].weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
+                 po_wk=pack_proj_tail(tt.proj_out.weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
                  fnw=_f32(blk.ff_norm.weight), fnb=_f32(blk.ff_norm.bias))
         for i, (a, nrm) in enumerate(zip(blk.attention_blocks, blk.norms)):
             d[f"qkv{i}"] = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous()
@@ -491,6 +509,5 @@ class MotionModule(HipModule):
             qkv = ops.gemm(u, p[f"qkv{i}"])
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
             t, u = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True, ln=ln[i + 1])
-        z = _ff_run(ctx, p, t, u, out_f32=False)
-        out = ops.gemm(z, p["po_w"], bias=p["po_b"], residual=x.view(-1, C), out_f32=True, colstats=H * W)
+        out = _ff_proj_run(ctx, p, t, u, p, x.view(-1, C), H * W)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))

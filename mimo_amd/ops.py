@@ -243,6 +243,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
 # kernel choice of this package the decision depends on the layer's width and on a fixed row threshold, never on how many
 # images share the launch beyond it (FF_FUSED_MIN_ROWS: below it the panel count cannot fill the chip).
 FF_FUSED = True
+FF_PROJ_FUSED = True   # ... and the block's output projection + residual folded into the same launch (mimo_ff_proj_fused)
 FF_FUSED_DIM = 320
 FF_FUSED_MIN_ROWS = 8192
 
@@ -260,6 +261,25 @@ def ff_fused(a, w1p, b1p, w2k, b2, residual):
     with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, residual, out)):
         L.call("mimo_ff_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(), _ptr(b2),
                residual.data_ptr(), residual.stride(0), out.data_ptr(), out.stride(0), M, C, _stream())
+    return out
+
+
+def ff_proj_fused(a, w1p, b1p, w2k, b2, residual, wpk, bp, x):
+    """fp32 [M, C] = x + (residual + FF(a)) @ Wp^T + bp in ONE launch (C = 320): ff_fused with the block's output projection
+    and its residual folded in; wpk = packing.pack_proj_tail(proj_out.weight)."""
+    _chk(a, "a")
+    M, C = a.shape
+    assert a.stride(1) == 1 and w1p.shape == (8 * C, C) and w2k.shape == (C, 4 * C) and wpk.shape == (C, C)
+    assert w1p.is_contiguous() and w2k.is_contiguous() and wpk.is_contiguous()
+    for r in (residual, x):
+        assert r.dtype == torch.float32 and r.shape == (M, C) and r.stride(1) == 1
+    out = torch.empty((M, C), device=a.device, dtype=torch.float32)
+    fl = 2 * M * C * (8 * C + 4 * C + C)
+    _count(fl)
+    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, wpk, residual, x, out)):
+        L.call("mimo_ff_proj_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(),
+               _ptr(b2), residual.data_ptr(), residual.stride(0), wpk.data_ptr(), _ptr(bp), x.data_ptr(), x.stride(0),
+               out.data_ptr(), out.stride(0), M, C, _stream())
     return out
 
 

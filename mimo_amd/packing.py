@@ -57,3 +57,19 @@ def pack_ff2_kperm(weight, dtype):
     idx = torch.tensor(ff2_kperm(), device=weight.device)
     w = weight.detach().float().reshape(co, k // 32, 32)[:, :, idx].reshape(co, k)
     return w.to(dtype).contiguous()
+
+
+def pack_proj_tail(weight, dtype):
+    """proj_out weight [C, C] (Linear, or a 1x1 conv reshaped) for mimo_ff_proj_fused: rows in tile order — tile q (64 rows) =
+    output columns 32q..32q+31 followed by 160+32q..160+32q+31, the two column halves the kernel's wave pairs own — and the
+    K axis permuted inside every 32-block like pack_ff2_kperm (its operand comes straight from accumulator registers)."""
+    co, k = weight.shape
+    assert co % 64 == 0 and co // 2 % 32 == 0 and k % 32 == 0
+    half = co // 2
+    rows = []
+    for q in range(co // 64):
+        rows += list(range(32 * q, 32 * q + 32)) + list(range(half + 32 * q, half + 32 * q + 32))
+    ridx = torch.tensor(rows, device=weight.device)
+    kidx = torch.tensor(ff2_kperm(), device=weight.device)
+    w = weight.detach().float()[ridx].reshape(co, k // 32, 32)[:, :, kidx].reshape(co, k)
+    return w.to(dtype).contiguous()

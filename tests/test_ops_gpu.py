@@ -412,6 +412,37 @@ def test_ff_fused_c320(dev, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [128, 8192 + 77, 33, 40000])
+def test_ff_proj_fused_c320(dev, dtype, M):
+    """mimo_ff_proj_fused (C = 320): x + (residual + FF(a)) Wp^T + bp in one launch vs the three launches it replaces and a
+    torch fp32 reference with the kernel's two half roundings (hidden activations, FF result)."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_ff2_kperm, pack_geglu, pack_proj_tail
+    C = 320
+    a = rnd((M, C), dev, dtype, 1)
+    w1 = rnd((8 * C, C), dev, torch.float32, 2, C ** -0.5)
+    b1 = rnd((8 * C,), dev, torch.float32, 3, 0.1)
+    w2 = rnd((C, 4 * C), dev, torch.float32, 4, (4 * C) ** -0.5)
+    b2 = rnd((C,), dev, torch.float32, 5, 0.1)
+    res = rnd((M, C), dev, torch.float32, 6)
+    wp = rnd((C, C), dev, torch.float32, 7, C ** -0.5)
+    bp = rnd((C,), dev, torch.float32, 8, 0.1)
+    x = rnd((M, C), dev, torch.float32, 9)
+    w1p, b1p = pack_geglu(w1, b1, dtype)
+    out = ops.ff_proj_fused(a, w1p, b1p, pack_ff2_kperm(w2, dtype), b2, res, pack_proj_tail(wp, dtype), bp, x)
+    assert out.shape == (M, C) and out.dtype == torch.float32
+    hcat = a.float() @ w1.to(dtype).float().t() + b1
+    hid = (hcat[:, :4 * C] * F.gelu(hcat[:, 4 * C:])).to(dtype).float()
+    z = (res + hid @ w2.to(dtype).float().t() + b2).to(dtype).float()
+    ref = x + z @ wp.to(dtype).float().t() + bp
+    assert rel_l2(out, ref) < ACC_TOL * 5  # fp32 output; the half roundings are replicated in the reference
+    zz = ops.gemm(ops.gemm(a, w1p, bias=b1p, geglu=True), w2.to(dtype).contiguous(), bias=b2, residual=res)
+    three = ops.gemm(zz, wp.to(dtype).contiguous(), bias=bp, residual=x, out_f32=True)
+    assert rel_l2(out, three) < OUT_TOL[dtype]
+    assert rel_l2(out[M // 2], ref[M // 2]) < 1e-4 and rel_l2(out[:, 161], ref[:, 161]) < 1e-4 and rel_l2(out[:, 7], ref[:, 7]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,B,spike", [(64, 1, 0), (100, 3, 0), (1024, 2, 0), (333, 2, 5), (4096, 1, 0)])
 def test_attention_single_head_d512(dev, dtype, N, B, spike):
     """The VAE mid-block attention: ONE head of d = 512 over the N tokens of an image (attn512_kernel: head dimension split

@@ -92,6 +92,19 @@ def ff(dev, dt):
         fl = 2 * M * C * 12 * C
         d = float((f1().float() - f2().float()).norm() / f2().float().norm())
         print(f"  M {M}: fused {best[0]:7.3f} ms ({fl/best[0]/1e9:6.0f} TF/s)   two launches {best[1]:7.3f} ms ({fl/best[1]/1e9:6.0f} TF/s)   rel_l2 {d:.2e}", flush=True)
+        from mimo_amd.packing import pack_proj_tail
+        wp = torch.randn(C, C, device=dev) * C ** -0.5
+        bp = torch.randn(C, device=dev) * 0.1
+        x = torch.randn(M, C, device=dev)
+        wpk, wph = pack_proj_tail(wp, dt), wp.to(dt).contiguous()
+        g1 = lambda: ops.ff_proj_fused(a, w1p, b1p, w2k, b2, res, wpk, bp, x)
+        g2 = lambda: ops.gemm(f2(), wph, bias=bp, residual=x, out_f32=True)
+        bb = [1e9, 1e9]
+        for _ in range(3):
+            bb[0] = min(bb[0], timeit(g1, iters=10, warm=2))
+            bb[1] = min(bb[1], timeit(g2, iters=10, warm=2))
+        d = float((g1() - g2()).norm() / g2().norm())
+        print(f"     + proj_out: fused {bb[0]:7.3f} ms   three launches {bb[1]:7.3f} ms   rel_l2 {d:.2e}", flush=True)
 
 
 def attn40_prio(dev, dt):
