@@ -208,6 +208,22 @@ int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const f
 int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
                        const float* b2, const float* residual, int64_t ldr, const void* Wp, const float* bp,
                        const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C, void* stream);
+/* The whole tail of a transformer block after its attention core in one launch: the attention output projection with its
+ * residual (+ the collapsed cross-attention as a per-image vector), the LayerNorm in front of the feed-forward, the
+ * feed-forward and the owning transformer's proj_out with its residual (BasicTransformerBlock.forward after attn1,
+ * src/models/attention.py:208-262, + Transformer3DModel.forward's end, src/models/transformer_3d.py:150-169; the
+ * TemporalTransformerBlock after its second attention, src/models/motion_module.py:240-262 + :170-184):
+ *   y = residual + O @ Wo^T + bo (+ img_bias[row / rows_per_img]);  n = LayerNorm(y) * ln_gamma + ln_beta
+ *   out[M, C] (fp32) = x + (y + FF(n)) @ Wp^T + bp
+ *   O: half16 attention output; Wstream: half16 [10 C, C] = [Wo with rows in tile order (pack_rows_tail) | W1 GEGLU-packed
+ *   with its K axis permuted (pack_ff2_kperm) | Wp as for mimo_ff_proj_fused] (mimo_amd.packing.pack_block_tail_stream);
+ *   y and n never reach memory.  img_bias: fp32 [ceil(M / rows_per_img), ldib] or NULL, rows_per_img >= 128.
+ *   MIMO_EINVAL unless C == 320. */
+int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* Wstream, const float* bo,
+                          const float* img_bias, int64_t ldib, int64_t rows_per_img, const float* residual, int64_t ldr,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1, const void* W2,
+                          const float* b2, const float* bp, const float* x, int64_t ldx, float* out, int64_t ldo,
+                          int64_t M, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional

@@ -46,7 +46,36 @@ struct FFArgs {
   const float* x;       // fp32 [M, ldx]: the block input (the residual of proj_out)
   float* out32;         // fp32 [M, ldo32]
   int64_t ldx, ldo32;
+  // MODE = 2: the attention output projection and the LayerNorm in front of the feed-forward folded in as well:
+  //   y = res + A @ Wo^T + bo (+ img_bias[row / rows_per_img]);  n = LayerNorm(y) * gamma + beta;  out32 = x + (y + FF(n)) @ Wp^T + bp
+  // (A = the attention output, res = the stream before the attention; W1 then carries the K permutation of pack_ff2_kperm)
+  // W1 is then ONE stream of 50 tiles of 64 rows: [Wo (rows in tile order like Wp, K axis natural) | W1 | Wp]
+  const float* bo;      // [C]
+  const float* img_bias;  // fp32 [nimg, ldib] or null
+  const float* ln_gamma;  // [C]
+  const float* ln_beta;   // [C]
+  int64_t ldib, rows_per_img;
+  float ln_eps;
+#ifdef MIMO_TUNE
+  unsigned long long* dbg;  // phase trace (tools/ff_trace.py) or null
+  int ablate;               // 1: no DMAs (stale tiles); 2: no MFMA phases (stream + barriers only); 3: GELU -> identity
+#endif
 };
+
+#ifdef MIMO_TUNE
+// two tracers of block 0: thread 0 (wave 0: row group 0, column half 0) fills entries [0, 2000), thread 256 (wave 4: column
+// half 1, the DMA issuer) [2000, 4000)
+#define FF_TRACE(g, idx, tag)                                                                                      \
+  do {                                                                                                             \
+    if ((g).dbg && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (idx) < 2000u)                                   \
+      (g).dbg[(threadIdx.x >> 8) * 2000u + (idx)++] =                                                              \
+          ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull);              \
+  } while (0)
+#define FF_ABLATE(g, n) ((g).ablate == (n))
+#else
+#define FF_TRACE(g, idx, tag) do { (void)(idx); } while (0)
+#define FF_ABLATE(g, n) false
+#endif
 
 template <int V>
 struct ICf {
@@ -58,16 +87,28 @@ constexpr int ROWB1 = C * 2;                  // bytes of a W1 row
 constexpr int W1_TILE = 64 * ROWB1;           // 40 KB
 constexpr int W2_TILE = C * 64;               // 320 rows x 32 k x 2 B = 20 KB
 constexpr int STAGE = W1_TILE + W2_TILE;      // 60 KB
-constexpr int BIAS_OFF = 2 * STAGE;           // b1 (8C floats), b2 (C floats), bp (C floats)
-constexpr int XCH_OFF = BIAS_OFF + (8 * C + 2 * C) * 4;
+constexpr int BIAS_OFF = 2 * STAGE;           // b1 (8C floats), b2, bp, bo, LN gamma, LN beta (C floats each)
+constexpr int XCH_OFF = BIAS_OFF + (8 * C + 5 * C) * 4;
 constexpr int NTAIL = C / 64;                 // W tiles of the folded output projection
 constexpr int LDS_BYTES = XCH_OFF + 2 * 8 * 1024;   // hidden-chunk exchange, double-buffered by step parity
 constexpr int BM = 128;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
-template <int DT, int TAIL>
+// An offset that must stay ONE register inside the panel loop: everything derived from it by adding constants then folds into
+// the instructions' immediate offsets.  (Left visible to the optimiser, every `offset + constant` is loop-invariant, gets
+// hoisted out of the panel loop as a value of its own and is parked in scratch across the main loop.)
+__device__ __forceinline__ unsigned pinned(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// MODE 0: feed-forward only (half output); 1: + the block's output projection; 2: + the attention output projection and
+// the LayerNorm in front (the whole tail of a transformer block after its attention core)
+template <int DT, int MODE>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
-  constexpr int NPOS = NSTEP + (TAIL ? NTAIL : 0);   // stream positions (W tiles of the W1 region) per panel
+  constexpr bool TAIL = MODE >= 1;
+  constexpr int NPRE = MODE == 2 ? NTAIL : 0;           // W tiles of the folded attention output projection
+  constexpr int NPOS = NPRE + NSTEP + (TAIL ? NTAIL : 0);   // stream positions (W tiles of the W1 region) per panel
   __shared__ __attribute__((aligned(16))) uint4 smem[LDS_BYTES / 16];  // ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,6 +120,11 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   for (int n = tid; n < 8 * C; n += 512) bias_lds[n] = g.b1 ? g.b1[n] : 0.f;
   for (int n = tid; n < C; n += 512) bias_lds[8 * C + n] = g.b2 ? g.b2[n] : 0.f;
   for (int n = tid; n < C; n += 512) bias_lds[9 * C + n] = (TAIL && g.bp) ? g.bp[n] : 0.f;
+  for (int n = tid; n < C; n += 512) {
+    bias_lds[10 * C + n] = (MODE == 2 && g.bo) ? g.bo[n] : 0.f;
+    bias_lds[11 * C + n] = MODE == 2 ? g.ln_gamma[n] : 0.f;
+    bias_lds[12 * C + n] = MODE == 2 ? g.ln_beta[n] : 0.f;
+  }
 
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -86,9 +132,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
     return r;
   };
-  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(8 * C) * (unsigned)ROWB1);
+  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(MODE == 2 ? NPOS * 64 : 8 * C) * (unsigned)ROWB1);
   const i32x4 rW2 = make_rsrc(g.W2, (unsigned)C * (unsigned)(HID * 2));
-  const i32x4 rWp = make_rsrc(TAIL ? g.Wp : g.W1, TAIL ? (unsigned)C * (unsigned)ROWB1 : 0u);
+  const i32x4 rWp = make_rsrc(MODE == 1 ? g.Wp : g.W1, MODE == 1 ? (unsigned)C * (unsigned)ROWB1 : 0u);
   constexpr unsigned OOBA = 0x80000000u;
 
   // ---- W stream.  Pieces of 1 KB per step: 0..39 = the W1 tile, 40..59 = the W2 slice; wave w moves pieces w, w + 8, ...
@@ -102,9 +148,12 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   //   W2 piece d: 16 rows x 64 B; lane l fetches row 16 d + (l >> 2), logical chunk (l & 3) ^ (2 * ((l >> 5) & 1))
   const unsigned w1_lane = ((unsigned)lane >> 3) * (unsigned)ROWB1 + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 3) & 7u)) << 4);
   const unsigned w2_lane = ((unsigned)lane >> 2) * (unsigned)(HID * 2) + ((((unsigned)lane & 3u) ^ (2u * (((unsigned)lane >> 5) & 1u))) << 4);
-  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_dst) {
+  auto dma = [&](const i32x4& r_, unsigned voff, unsigned soff, unsigned lds_dst) {
+    // (every scalar operand said to be scalar: under register pressure the compiler otherwise parks descriptors in VGPRs)
+    const i32x4 r = {__builtin_amdgcn_readfirstlane(r_.x), __builtin_amdgcn_readfirstlane(r_.y),
+                     __builtin_amdgcn_readfirstlane(r_.z), __builtin_amdgcn_readfirstlane(r_.w)};
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(lds_dst) : "memory", "m0");
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory", "m0");
   };
   const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
   const unsigned total = my_panels * (unsigned)NPOS;
@@ -115,13 +164,15 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   // the step's MFMAs at once — the two waves of a SIMD then alternate between the matrix pipe and VALU / issue work
   // with ONE code path (a second, reordered path for half 0 cost 15 scratch reloads per step at the 256-register cap).
   auto issue_next = [&]() {
-    if (sh == 1u) {
+    if (sh == 1u && !(FF_ABLATE(g, 1) && ld_t >= 2u)) {
       const bool live1 = ld_t < total;
       const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;      // position ld_t - 1 inside its panel
-      const bool live2 = ld_t >= 1u && ld_t <= total && j2 < (unsigned)NSTEP;  // (the projection tiles have no W2 slice)
+      // (only the feed-forward positions have a W2 slice)
+      const bool live2 = ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NSTEP);
       const unsigned dst1 = smem_base + (ld_t & 1u) * (unsigned)STAGE;
       const unsigned dst2 = smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE;
-      const bool tail_tile = TAIL && ld_j >= (unsigned)NSTEP;
+      // MODE 2: the W1 region's tiles are one stream in position order; MODE 1: the projection tiles are a second tensor
+      const bool tail_tile = MODE == 1 && ld_j >= (unsigned)NSTEP;
       const i32x4 r1 = tail_tile ? rWp : rW1;
       const unsigned tile = tail_tile ? ld_j - (unsigned)NSTEP : ld_j;
 #pragma unroll
@@ -133,12 +184,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
           const unsigned d = pr + 4u * i;
-          dma(rW2, w2_lane, j2 * 64u + d * (16u * HID * 2u), dst2 + d * 1024u);
+          dma(rW2, w2_lane, (j2 - (unsigned)NPRE) * 64u + d * (16u * HID * 2u), dst2 + d * 1024u);
         }
       }
     }
-    ++ld_t;
-    ld_j = ld_j + 1 == (unsigned)NPOS ? 0u : ld_j + 1;
+    // (wave-uniform by construction; said explicitly, the descriptors and LDS targets derived from them must stay scalar)
+    ld_t = __builtin_amdgcn_readfirstlane(ld_t + 1u);
+    ld_j = __builtin_amdgcn_readfirstlane(ld_j + 1u == (unsigned)NPOS ? 0u : ld_j + 1u);
   };
 
   // W1 fragment: tile row ni * 16 + li, logical chunk 4 ks + lg; this wave's tiles are ni = 2 sh (value), 2 sh + 1 (gate)
@@ -155,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   __syncthreads();  // bias image complete (the compiler drains its own loads; the DMAs are invisible to it)
 
   unsigned t = 0;
+  [[maybe_unused]] unsigned tr = 0;
   for (unsigned panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
     const int64_t M0 = (int64_t)panel * BM;
     const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
@@ -166,23 +219,167 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + C) * 2), 0x00020000);
     // ---- this row group's 32 x 320 slice of A in MFMA operand layout (both column halves hold it) ----
     uint4 fa[2][KS];
-    const unsigned a_off = (unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2);
+    const unsigned a_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2));
     const unsigned a_mi = (unsigned)(16 * g.lda * 2);
+    auto load_a = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + mi * a_mi + ks * 64, 0, 0));
-    // ---- FF2 accumulators = residual + b2 for columns [160 sh, 160 sh + 160): lane (li, lg) owns 4 consecutive columns ----
+        for (int ks = 0; ks < KS; ++ks)
+          fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, 0));
+    };
+    if constexpr (MODE != 2) load_a();   // (MODE 2 loads it after the per-image vector: 80 registers fewer in flight)
+    // ---- FF2 accumulators for columns [160 sh, 160 sh + 160): lane (li, lg) owns 4 consecutive columns of row li of each
+    // 16-row tile.  MODE < 2: residual + b2.  MODE = 2: first the attention output projection accumulates on residual + bo
+    // (+ the per-image vector), see below ----
     f32x4 acc2[10][2];
-    const unsigned r_off = (unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 160 * sh + 4 * lg) * 4);
+    const unsigned r_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 160 * sh + 4 * lg) * 4));
+    const unsigned bcol = pinned(BIAS_Q + 40u * sh + (unsigned)lg);  // this lane's column group inside a C-wide vector of the bias image
     const unsigned r_mi = (unsigned)(16 * g.ldr * 4);
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) {
-      const f32x4 bv = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(2 * C) + 40u * sh + (unsigned)(4 * nt + lg)]);
+      const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((MODE == 2 ? 10 : 8) * C / 4 + 4 * nt)]);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + mi * r_mi + nt * 64, 0, 0)) + bv;
+        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, 0)) + bv;
+    }
+    // one 64-row tile of a [C, C] weight in the W1 region of stage t & 1 (rows in the tile order of pack_proj_tail: this
+    // wave's output columns 32 q .. 32 q + 31 of its 160 are the tile's n-tiles 2 sh, 2 sh + 1) times the operand in fa
+    auto proj = [&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc2[2 * q + ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], acc2[2 * q + ni][mi]);
+        }
+      }
+    };
+    // the partner wave's five k-steps of a [32 x 320] operand that both waves hold half of in accumulator layout come
+    // through the exchange buffers, one k-step per round; own(kk, mi) = this wave's k-step kk (0..4) as packed halfs
+    auto exchange_operand = [&](auto&& own) {
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const uint4 m0 = own(kk, 0), m1 = own(kk, 1);
+        smem[xch_mine] = m0;
+        smem[xch_mine + XCH_BUF] = m1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const uint4 p0 = smem[xch_peer], p1 = smem[xch_peer + XCH_BUF];
+        if (sh == 0) {
+          fa[0][kk] = m0; fa[1][kk] = m1; fa[0][5 + kk] = p0; fa[1][5 + kk] = p1;
+        } else {
+          fa[0][kk] = p0; fa[1][kk] = p1; fa[0][5 + kk] = m0; fa[1][5 + kk] = m1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // both halves have read before the next round writes
+      }
+    };
+    if constexpr (MODE == 2) {
+      FF_TRACE(g, tr, 10);
+      if (g.img_bias) {
+        // the per-image vector (the collapsed cross-attention of the spatial blocks): the same 40 values per lane for every
+        // row of an image; rows_per_img >= 128, so a panel holds rows of at most two images
+        const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
+        const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
+        const int64_t img0 = M0 / g.rows_per_img;                                   // (scalar, once per panel)
+        const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);                  // panel row where the next image starts
+        const unsigned ib_off = (unsigned)((img0 * g.ldib + 160 * sh + 4 * lg) * 4);
+        if (next0 >= BM) {
+#pragma unroll
+          for (int nt = 0; nt < 10; ++nt) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, ib_off + nt * 64, 0, 0));
+            acc2[nt][0] += v;
+            acc2[nt][1] += v;
+          }
+        } else {
+          const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const unsigned o = ib_off + ((int)(pr * 32) + 16 * mi + li >= next0 ? step : 0u);
+#pragma unroll
+            for (int nt = 0; nt < 10; ++nt)
+              acc2[nt][mi] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + nt * 64, 0, 0));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a();
+      FF_TRACE(g, tr, 11);
+      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel); every tile: wait, barrier, issue the
+      // next position, multiply
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<0>{}); ++t; FF_TRACE(g, tr, 12);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<1>{}); ++t; FF_TRACE(g, tr, 13);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t; FF_TRACE(g, tr, 14);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t; FF_TRACE(g, tr, 15);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t; FF_TRACE(g, tr, 16);
+      // LayerNorm over the row's 320 columns: this wave holds 160 of them, 40 per lane.  Local sum and local centred sum of
+      // squares, combined with the partner's by the pairwise update (mean = (s0 + s1) / 320, M2 = q0 + q1 + 80 (m0 - m1)^2);
+      // both waves evaluate the combination with the halves in the same order: bit-identical statistics.
+      float rs[2], rq[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt) sum += (acc2[nt][mi][0] + acc2[nt][mi][1]) + (acc2[nt][mi][2] + acc2[nt][mi][3]);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float ml = sum * (1.f / 160.f);
+        float qq = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = acc2[nt][mi][r] - ml;
+            qq = fmaf(d, d, qq);
+          }
+        qq += __shfl_xor(qq, 16, 64);
+        qq += __shfl_xor(qq, 32, 64);
+        rs[mi] = sum; rq[mi] = qq;
+      }
+      smem[xch_mine] = make_uint4(__float_as_uint(rs[0]), __float_as_uint(rq[0]), __float_as_uint(rs[1]), __float_as_uint(rq[1]));
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const uint4 pst = smem[xch_peer];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // read before the operand rounds rewrite the buffer
+      FF_TRACE(g, tr, 17);
+      float mean[2], rstd[2];
+      {
+        const float ps[2] = {__uint_as_float(pst.x), __uint_as_float(pst.z)}, pq[2] = {__uint_as_float(pst.y), __uint_as_float(pst.w)};
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const float s0 = sh == 0 ? rs[mi] : ps[mi], s1 = sh == 0 ? ps[mi] : rs[mi];
+          const float q0 = sh == 0 ? rq[mi] : pq[mi], q1 = sh == 0 ? pq[mi] : rq[mi];
+          const float dm = (s0 - s1) * (1.f / 160.f);
+          mean[mi] = (s0 + s1) * (1.f / 320.f);
+          rstd[mi] = rsqrtf(((q0 + q1) + 80.f * dm * dm) * (1.f / 320.f) + g.ln_eps);
+        }
+      }
+      // n = LayerNorm(y) * gamma + beta as the feed-forward's MFMA operand, straight from the accumulators (W1 carries the
+      // K permutation of the accumulator layout)
+      exchange_operand([&](int kk, int mi) -> uint4 {
+        uint32_t w[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned cq = (unsigned)(4 * (2 * kk + h));
+          const f32x4 gm = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(11 * C / 4) + cq]);
+          const f32x4 bt = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(12 * C / 4) + cq]);
+          const f32x4 v = (acc2[2 * kk + h][mi] - mean[mi]) * rstd[mi] * gm + bt;
+          w[2 * h] = pack2<DT>(v[0], v[1]);
+          w[2 * h + 1] = pack2<DT>(v[2], v[3]);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+      });
+      FF_TRACE(g, tr, 18);
+      // the feed-forward accumulates on y + b2
+#pragma unroll
+      for (int nt = 0; nt < 10; ++nt) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(8 * C / 4 + 4 * nt)]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc2[nt][mi] += bv;
+      }
     }
 
     u32x2 hm_prev[2] = {{0u, 0u}, {0u, 0u}};  // this wave's half of the previous chunk (packed), kept for its FF2
@@ -219,8 +416,14 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const f32x4 v = acc1[0][mi] + bval, gt = acc1[1][mi] + bgate;
-        hm_prev[mi].x = pack2<DT>(v[0] * gelu_erf_f(gt[0]), v[1] * gelu_erf_f(gt[1]));
-        hm_prev[mi].y = pack2<DT>(v[2] * gelu_erf_f(gt[2]), v[3] * gelu_erf_f(gt[3]));
+        if (FF_ABLATE(g, 3)) {
+          hm_prev[mi].x = pack2<DT>(v[0] * gt[0], v[1] * gt[1]);
+          hm_prev[mi].y = pack2<DT>(v[2] * gt[2], v[3] * gt[3]);
+        } else {
+          const f32x4 h = v * gelu_erf_4(gt);
+          hm_prev[mi].x = pack2<DT>(h[0], h[1]);
+          hm_prev[mi].y = pack2<DT>(h[2], h[3]);
+        }
       }
       smem[xch_mine + (t & 1u) * XCH_BUF] = make_uint4(hm_prev[0].x, hm_prev[0].y, hm_prev[1].x, hm_prev[1].y);
     };
@@ -250,17 +453,26 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     issue_next();
     ff1(0);
     ++t;
+    FF_TRACE(g, tr, 19);
     // steady state: W1 tile t and W2 slice t - 1 have landed (every DMA a wave issued is older than its wait), the
     // partner's half of chunk t - 1 is in the exchange buffer, every wave is done with the stages about to be refilled
     for (int j = 1; j < NSTEP; ++j, ++t) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      FF_TRACE(g, tr, 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      FF_TRACE(g, tr, 2);
+      asm volatile("s_barrier" ::: "memory");
+      FF_TRACE(g, tr, 3);
       issue_next();
-      ff2((t + 1u) & 1u, hm_prev);
+      FF_TRACE(g, tr, 4);
+      if (!FF_ABLATE(g, 2)) ff2((t + 1u) & 1u, hm_prev);
       __builtin_amdgcn_sched_barrier(0);  // FF1's fragment reads must not be hoisted into FF2 (register pressure)
-      ff1(j);
+      FF_TRACE(g, tr, 5);
+      if (!FF_ABLATE(g, 2)) ff1(j);
+      FF_TRACE(g, tr, 6);
     }
     // drain: FF2 of the panel's last chunk (its W2 slice was issued in the last step)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FF_TRACE(g, tr, 20);
     if constexpr (TAIL) issue_next();  // second projection tile (the first one was issued in the last FF step and has landed)
     ff2((t + 1u) & 1u, hm_prev);
     const int row0 = (int)pr * 32 + li;
@@ -286,52 +498,24 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
           (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
       const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(g.out32 + M0 * g.ldo32), 0, (int)(((rows_valid - 1) * g.ldo32 + C) * 4), 0x00020000);
-      auto zop = [&](int kk, int mi) -> uint4 {  // k-step kk (0..4) of this wave's own columns
-        const f32x4 a0 = acc2[2 * kk][mi], a1 = acc2[2 * kk + 1][mi];
-        return make_uint4(pack2<DT>(a0[0], a0[1]), pack2<DT>(a0[2], a0[3]), pack2<DT>(a1[0], a1[1]), pack2<DT>(a1[2], a1[3]));
-      };
       // (the partner may still be reading this wave's half of the last chunk: no exchange buffer is rewritten before everyone
       // is through its drain)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-      for (int kk = 0; kk < 5; ++kk) {
-        const uint4 m0 = zop(kk, 0), m1 = zop(kk, 1);
-        smem[xch_mine] = m0;
-        smem[xch_mine + XCH_BUF] = m1;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const uint4 p0 = smem[xch_peer], p1 = smem[xch_peer + XCH_BUF];
-        if (sh == 0) {
-          fa[0][kk] = m0; fa[1][kk] = m1; fa[0][5 + kk] = p0; fa[1][5 + kk] = p1;
-        } else {
-          fa[0][kk] = p0; fa[1][kk] = p1; fa[0][5 + kk] = m0; fa[1][5 + kk] = m1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // both halves have read before the next round writes
-      }
+      exchange_operand([&](int kk, int mi) -> uint4 {  // k-step kk (0..4) of this wave's own columns
+        const f32x4 a0 = acc2[2 * kk][mi], a1 = acc2[2 * kk + 1][mi];
+        return make_uint4(pack2<DT>(a0[0], a0[1]), pack2<DT>(a0[2], a0[3]), pack2<DT>(a1[0], a1[1]), pack2<DT>(a1[2], a1[3]));
+      });
+      FF_TRACE(g, tr, 21);
       // accumulators re-initialised with the block input + bias
-      const unsigned x_off = (unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 160 * sh + 4 * lg) * 4);
+      const unsigned x_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 160 * sh + 4 * lg) * 4));
       const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
 #pragma unroll
       for (int nt = 0; nt < 10; ++nt) {
-        const f32x4 bv = __builtin_bit_cast(f32x4, smem[BIAS_Q + (unsigned)(9 * C / 4) + 40u * sh + (unsigned)(4 * nt + lg)]);
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(9 * C / 4 + 4 * nt)]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
-          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + mi * x_mi + nt * 64, 0, 0)) + bv;
+          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, 0)) + bv;
       }
-      // five tiles of Wp: tile q holds this wave's output columns 32 q .. 32 q + 31 (of its 160) as its n-tiles 2 sh, 2 sh + 1
-      auto proj = [&](auto q_c) {
-        constexpr int q = decltype(q_c)::value;
-        const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) acc2[2 * q + ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], acc2[2 * q + ni][mi]);
-          }
-        }
-      };
       // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, issue the next, multiply
       proj(ICf<0>{});
       ++t;
@@ -339,13 +523,17 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t;
+      FF_TRACE(g, tr, 22);
       static_assert(NTAIL == 5, "projection tiles are spelled out");
+      // (one lane-dependent offset; the row tile travels in the scalar offset, the column tile in the immediate)
+      const unsigned o_off = pinned(((unsigned)row0 * (unsigned)g.ldo32 + 160u * sh + 4u * (unsigned)lg) * 4u);
+      const unsigned o_mi = 16u * (unsigned)g.ldo32 * 4u;
 #pragma unroll
       for (int nt = 0; nt < 10; ++nt)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
-                                                 ((unsigned)(row0 + 16 * mi) * (unsigned)g.ldo32 + 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)lg) * 4u, 0, 0);
+                                                 o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
@@ -355,21 +543,30 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-static int ff_launch(int dtype, FFArgs& g, bool tail, void* stream) {
+template <int DT>
+static void ff_launch_dt(const FFArgs& g, int mode, unsigned grid, hipStream_t st) {
+  if (mode == 2) hipLaunchKernelGGL((ff_fused_kernel<DT, 2>), dim3(grid), dim3(512), 0, st, g);
+  else if (mode == 1) hipLaunchKernelGGL((ff_fused_kernel<DT, 1>), dim3(grid), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((ff_fused_kernel<DT, 0>), dim3(grid), dim3(512), 0, st, g);
+}
+
+#ifdef MIMO_TUNE
+extern "C" unsigned long long* mimo_tune_trace_buf();
+#endif
+
+static int ff_launch(int dtype, FFArgs& g, int mode, void* stream) {
+#ifdef MIMO_TUNE
+  g.dbg = tune_env("MIMO_FF_TRACE", 0) ? mimo_tune_trace_buf() : nullptr;
+  g.ablate = tune_env("MIMO_FF_ABLATE", 0);
+#endif
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const int64_t npanels = (g.M + BM - 1) / BM;
   const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIMO_F16) {
-    if (tail) hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16, 1>), dim3(grid), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((ff_fused_kernel<MIMO_F16, 0>), dim3(grid), dim3(512), 0, st, g);
-  } else if (dtype == MIMO_BF16) {
-    if (tail) hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16, 1>), dim3(grid), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((ff_fused_kernel<MIMO_BF16, 0>), dim3(grid), dim3(512), 0, st, g);
-  } else {
-    return MIMO_EDTYPE;
-  }
+  if (dtype == MIMO_F16) ff_launch_dt<MIMO_F16>(g, mode, grid, st);
+  else if (dtype == MIMO_BF16) ff_launch_dt<MIMO_BF16>(g, mode, grid, st);
+  else return MIMO_EDTYPE;
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }
@@ -385,7 +582,7 @@ extern "C" int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* 
   FFArgs g{};
   g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
   g.out = (uint16_t*)out; g.lda = lda; g.ldr = ldr; g.ldo = ldo; g.M = M;
-  return ff_launch(dtype, g, false, stream);
+  return ff_launch(dtype, g, 0, stream);
 }
 
 extern "C" int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
@@ -403,5 +600,29 @@ extern "C" int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const v
   g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
   g.lda = lda; g.ldr = ldr; g.M = M;
   g.Wp = (const uint16_t*)Wp; g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo;
-  return ff_launch(dtype, g, true, stream);
+  return ff_launch(dtype, g, 1, stream);
+}
+
+extern "C" int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* Wstream, const float* bo,
+                                     const float* img_bias, int64_t ldib, int64_t rows_per_img, const float* residual,
+                                     int64_t ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1,
+                                     const void* W2, const float* b2, const float* bp, const float* x, int64_t ldx,
+                                     float* out, int64_t ldo, int64_t M, int C_, void* stream) {
+  if (!O || !Wstream || !residual || !ln_gamma || !ln_beta || !W2 || !x || !out || M <= 0) return MIMO_EINVAL;
+  if (C_ != C) return MIMO_EINVAL;
+  if (img_bias && (rows_per_img < BM || (ldib & 3) || !aligned16(img_bias))) return MIMO_EINVAL;  // (<= two images per panel)
+  if ((ldo_in & 7) || (ldr & 3) || (ldx & 3) || (ldo & 3) || !aligned16(O) || !aligned16(Wstream) || !aligned16(W2) ||
+      !aligned16(residual) || !aligned16(x) || !aligned16(out))
+    return MIMO_EINVAL;
+  if (((M - 1) * ldo_in + C) * 2 >= 0x80000000LL || ((M - 1) * ldr + C) * 4 >= 0x100000000LL || ((M - 1) * ldx + C) * 4 >= 0x100000000LL ||
+      ((M - 1) * ldo + C) * 4 >= 0x100000000LL)
+    return MIMO_EINVAL;
+  if (img_bias && (((M + rows_per_img - 1) / rows_per_img - 1) * ldib + C) * 4 >= 0x80000000LL) return MIMO_EINVAL;
+  FFArgs g{};
+  g.A = (const uint16_t*)O; g.W1 = (const uint16_t*)Wstream; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
+  g.lda = ldo_in; g.ldr = ldr; g.M = M;
+  g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo;
+  g.bo = bo; g.img_bias = img_bias; g.ldib = ldib; g.rows_per_img = img_bias ? rows_per_img : 1;
+  g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps;
+  return ff_launch(dtype, g, 2, stream);
 }

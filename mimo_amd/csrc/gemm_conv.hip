@@ -182,8 +182,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           // gate tile = the next 16 packed columns; identical lane mapping
           const int ng = (ni + 1 < NR) ? ni + 1 : ni;
           const f32x4 gt = acc[ng][mi] + bv[ng];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
+          v *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt : gelu_erf_4(gt);
         }
         if (do_silu) {
 #pragma unroll
@@ -242,8 +241,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           if (GEGLU) {
             const int ng = ni + 1 < NR ? ni + 1 : ni;
             const f32x4 gt = acc[ng][mi] + bv[ng];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[u][r] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt[r] : gelu_erf_f(gt[r]);
+            v[u] *= MIMO_ABLATE(g, F_ABL_NO_GELU) ? gt : gelu_erf_4(gt);
           }
           if (do_silu) {
 #pragma unroll
@@ -1176,6 +1174,7 @@ inline unsigned long long* trace_buf() {
   }();
   return buf;
 }
+extern "C" unsigned long long* mimo_tune_trace_buf() { return trace_buf(); }   // (for the other translation units)
 // copies the trace of the most recent traced launch to `dst` (n entries <= 4096) and clears the device buffer
 extern "C" int mimo_tune_trace(unsigned long long* dst, int n) {
   if (!trace_buf() || n > 4096) return MIMO_EINVAL;

@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_stream_kernel(const Args
         for (int pr = 0; pr < 2; ++pr) {  // (value, gate) = MFMA tiles (2 pr, 2 pr + 1) -> output columns 16 pr ..
           const f32x4 v = acc[2 * pr][mi] + bv[2 * pr], gt = acc[2 * pr + 1][mi] + bv[2 * pr + 1];
           u32x2 o;
-          o.x = pack2<DT>(v[0] * gelu_erf_f(gt[0]), v[1] * gelu_erf_f(gt[1]));
-          o.y = pack2<DT>(v[2] * gelu_erf_f(gt[2]), v[3] * gelu_erf_f(gt[3]));
+          const f32x4 h = v * gelu_erf_4(gt);
+          o.x = pack2<DT>(h[0], h[1]);
+          o.y = pack2<DT>(h[2], h[3]);
           *reinterpret_cast<u32x2*>(pw + pr * 32) = o;
         }
       } else {

@@ -58,6 +58,8 @@ SIGNATURES = {
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
     "mimo_ff_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
     "mimo_ff_proj_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
+    "mimo_block_tail_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
+                              c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
     "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
     "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
+from .packing import pack_block_tail_stream, pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
 
 
 LOG2E = 1.4426950408889634
@@ -305,6 +305,20 @@ def _ff_proj_run(ctx, p, y_f32, n3, proj, x_f32, colstats):
     return ops.gemm(z, proj["po_w"], bias=proj["po_b"], residual=x_f32, out_f32=True, colstats=colstats)
 
 
+def _block_tail_run(ctx, p, o, t, proj, x_f32, keys, ln_eps, img_bias=None, rows_per_img=1):
+    """Everything after a block's attention core + the owning transformer's proj_out in one launch (C = 320), or None when
+    the fused kernel does not apply.  keys = (to_out bias, LN gamma, LN beta) names in p; proj["tail_ws"] = the weight stream."""
+    ws = proj.get("tail_ws")
+    if not (ops.BLOCK_TAIL_FUSED and ops.FF_PROJ_FUSED and ws is not None and _ff_fusable(p, o, False)):
+        return None
+    # (the kernel's per-image vector: 16-byte aligned rows, at most two images per 128-row panel; both conditions are
+    # properties of the model and the frame size, not of the batch: a sharded unit and the full launch decide alike)
+    if img_bias is not None and (img_bias.data_ptr() % 16 or img_bias.stride(0) % 4 or rows_per_img < 128):
+        return None
+    return ops.block_tail_fused(o, ws, p[keys[0]], t, p[keys[1]], p[keys[2]], ln_eps, p["ff1_b"], p["ff2_wk"], p["ff2_b"],
+                                proj["po_b"], x_f32, img_bias=img_bias, rows_per_img=rows_per_img)
+
+
 class SpatialTransformerBlock(HipModule):
     """mode None: plain; 'write': bank norm1(x) (reference UNet); 'read': cond rows attend [self || bank]."""
 
@@ -374,6 +388,11 @@ class SpatialTransformerBlock(HipModule):
         else:
             o = ops.attention(q, k, v, self.heads, q_prescaled=True)
         s, e = self.attn2_slice
+        if proj is not None:
+            out = _block_tail_run(ctx, p, o.view(-1, C), t, proj, x, ("o_b", "n3w", "n3b"), self.norm3.eps,
+                                  img_bias=ctx.attn2[:, s:e], rows_per_img=ctx.F * N)
+            if out is not None:
+                return out
         # to_out + collapsed attn2 + residual, with norm3 of the result fused into the same epilogue (C = 320)
         y, n3 = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
                          rows_per_img=ctx.F * N, residual=t, out_f32=True,
@@ -409,7 +428,12 @@ class SpatialTransformer(HipModule):
 
     def _pack(self, dt):
         C = self.proj_in.out_channels
+        blk = self.transformer_blocks[0]
+        fusable = C == ops.FF_FUSED_DIM and self.proj_out.out_channels == C
         return dict(g=_f32(self.norm.weight), b=_f32(self.norm.bias),
+                    tail_ws=pack_block_tail_stream(blk.attn1.to_out[0].weight,
+                                                   pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, dt)[0],
+                                                   self.proj_out.weight.detach().reshape(C, -1), dt) if fusable else None,
                     pi_w=self.proj_in.weight.detach().reshape(C, -1).to(dt).contiguous(), pi_b=_f32(self.proj_in.bias),
                     po_w=self.proj_out.weight.detach().reshape(self.proj_out.out_channels, -1).to(dt).contiguous(),
                     po_b=_f32(self.proj_out.bias),
@@ -486,6 +510,8 @@ class MotionModule(HipModule):
                  ff2_w=h(blk.ff.net[2].weight), ff2_b=_f32(blk.ff.net[2].bias),
                  ff2_wk=pack_ff2_kperm(blk.ff.net[2].weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
                  po_wk=pack_proj_tail(tt.proj_out.weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
+                 tail_ws=pack_block_tail_stream(blk.attention_blocks[1].to_out[0].weight, ff1_w, tt.proj_out.weight, dt)
+                 if self.dim == ops.FF_FUSED_DIM else None,
                  fnw=_f32(blk.ff_norm.weight), fnb=_f32(blk.ff_norm.bias))
         for i, (a, nrm) in enumerate(zip(blk.attention_blocks, blk.norms)):
             d[f"qkv{i}"] = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous()
@@ -504,10 +530,17 @@ class MotionModule(HipModule):
         # every LayerNorm (+ positional encoding) rides in the epilogue of the GEMM that produces its input
         ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], pe=p[f"pe{i}"], rows_per_frame=HW, pe_frames=ctx.F) for i in range(2)]
         ln.append(dict(gamma=p["fnw"], beta=p["fnb"]))
+        blk_eps = self.temporal_transformer.transformer_blocks[0].ff_norm.eps
         t, u = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=ln[0])
+        out = None
         for i in range(2):
             qkv = ops.gemm(u, p[f"qkv{i}"])
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
+            if i == 1:  # ... + to_out + residual + LayerNorm + feed-forward + proj_out + residual: one launch at C = 320
+                out = _block_tail_run(ctx, p, o, t, p, x.view(-1, C), ("o_b1", "fnw", "fnb"), blk_eps)
+                if out is not None:
+                    break
             t, u = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True, ln=ln[i + 1])
-        out = _ff_proj_run(ctx, p, t, u, p, x.view(-1, C), H * W)
+        if out is None:
+            out = _ff_proj_run(ctx, p, t, u, p, x.view(-1, C), H * W)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))

@@ -21,6 +21,7 @@ COUNTER = None
 # Optional per-launch HIP-event brackets of the MFMA kernels (bench.py roofline of the dominant kernel family):
 # EVENTS = [] makes gemm()/conv2d()/attention() record (family, start event, end event, flops) on the launch stream.
 EVENTS = None
+TAGS = None   # with EVENTS: a parallel list of shape tags (tools/forward_bound.py's per-shape table)
 
 
 def _count(flops):
@@ -35,8 +36,8 @@ def _nbytes(*tensors):
 
 
 class _Bracket:
-    def __init__(self, family, flops, nbytes=0):
-        self.family, self.flops, self.nbytes = family, flops, nbytes
+    def __init__(self, family, flops, nbytes=0, tag=""):
+        self.family, self.flops, self.nbytes, self.tag = family, flops, nbytes, tag
 
     def __enter__(self):
         if EVENTS is not None:
@@ -48,6 +49,8 @@ class _Bracket:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             EVENTS.append((self.family, self.e0, e1, self.flops, self.nbytes))
+            if TAGS is not None:
+                TAGS.append(self.tag)
         return False
 
 
@@ -219,7 +222,8 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     if fuse_ln:
         ln_out = torch.empty((M, N), device=a.device, dtype=a.dtype)
     _count(2 * M * N * K)
-    with _Bracket("gemm_kernel", 2 * M * N * K, M * K * a.element_size() + _nbytes(w, out, residual, ln_out, cs)):
+    with _Bracket("gemm_kernel", 2 * M * N * K, M * K * a.element_size() + _nbytes(w, out, residual, ln_out, cs),
+                  f"gemm M{M} N{N} K{K}{' geglu' if geglu else ''}{' ln' if fuse_ln else ''}{' f32' if out_f32 else ''}"):
         ws = _workspace(a.device)
         if cs is None and ln_out is None:
             L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
@@ -243,7 +247,8 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
 # kernel choice of this package the decision depends on the layer's width and on a fixed row threshold, never on how many
 # images share the launch beyond it (FF_FUSED_MIN_ROWS: below it the panel count cannot fill the chip).
 FF_FUSED = True
-FF_PROJ_FUSED = True   # ... and the block's output projection + residual folded into the same launch (mimo_ff_proj_fused)
+FF_PROJ_FUSED = True      # ... and the block's output projection + residual folded into the same launch (mimo_ff_proj_fused)
+BLOCK_TAIL_FUSED = True   # ... and the attention output projection + the LayerNorm in front (mimo_block_tail_fused)
 FF_FUSED_DIM = 320
 FF_FUSED_MIN_ROWS = 8192
 
@@ -258,7 +263,7 @@ def ff_fused(a, w1p, b1p, w2k, b2, residual):
     out = torch.empty((M, C), device=a.device, dtype=a.dtype)
     fl = 2 * M * C * (8 * C + 4 * C)
     _count(fl)
-    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, residual, out)):
+    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, residual, out), f"ff_fused M{M}"):
         L.call("mimo_ff_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(), _ptr(b2),
                residual.data_ptr(), residual.stride(0), out.data_ptr(), out.stride(0), M, C, _stream())
     return out
@@ -276,10 +281,35 @@ def ff_proj_fused(a, w1p, b1p, w2k, b2, residual, wpk, bp, x):
     out = torch.empty((M, C), device=a.device, dtype=torch.float32)
     fl = 2 * M * C * (8 * C + 4 * C + C)
     _count(fl)
-    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, wpk, residual, x, out)):
+    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, wpk, residual, x, out), f"ff_proj_fused M{M}"):
         L.call("mimo_ff_proj_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(),
                _ptr(b2), residual.data_ptr(), residual.stride(0), wpk.data_ptr(), _ptr(bp), x.data_ptr(), x.stride(0),
                out.data_ptr(), out.stride(0), M, C, _stream())
+    return out
+
+
+def block_tail_fused(o, wstream, bo, residual, ln_gamma, ln_beta, ln_eps, b1p, w2k, b2, bp, x, img_bias=None, rows_per_img=1):
+    """fp32 [M, C] = x + (y + FF(LayerNorm(y))) @ Wp^T + bp with y = residual + o @ Wo^T + bo (+ img_bias per image) in ONE
+    launch (C = 320): everything a transformer block does after its attention core plus the owning transformer's proj_out;
+    wstream = packing.pack_block_tail_stream(to_out.weight, GEGLU-packed FF1, proj_out.weight)."""
+    _chk(o, "o")
+    M, C = o.shape
+    assert o.stride(1) == 1 and wstream.shape == (10 * C, C) and w2k.shape == (C, 4 * C) and wstream.is_contiguous() and w2k.is_contiguous()
+    for r in (residual, x):
+        assert r.dtype == torch.float32 and r.shape == (M, C) and r.stride(1) == 1
+    ldib = 0
+    if img_bias is not None:
+        assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32 and img_bias.shape[1] == C
+        assert img_bias.shape[0] * rows_per_img >= M
+        ldib = img_bias.stride(0)
+    out = torch.empty((M, C), device=o.device, dtype=torch.float32)
+    fl = 2 * M * C * (C + 8 * C + 4 * C + C)
+    _count(fl)
+    with _Bracket("gemm_kernel", fl, _nbytes(o, wstream, w2k, residual, x, out), f"block_tail_fused M{M}"):
+        L.call("mimo_block_tail_fused", dt_code(o.dtype), o.data_ptr(), o.stride(0), wstream.data_ptr(), _ptr(bo), _ptr(img_bias),
+               ldib, rows_per_img, residual.data_ptr(), residual.stride(0), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps),
+               _ptr(b1p), w2k.data_ptr(), _ptr(b2), _ptr(bp), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, C,
+               _stream())
     return out
 
 
@@ -328,7 +358,9 @@ def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=
         cs = torch.empty((M // 32, 2, cout), device=x.device, dtype=torch.float32)
     fl = 2 * n * Ho * Wo * cout * (ksize * ksize * cin + cin2)
     _count(fl)
-    with _Bracket("gemm_kernel", fl, _nbytes(x, x2, w, out, residual, cs)):
+    with _Bracket("gemm_kernel", fl, _nbytes(x, x2, w, out, residual, cs),
+                  f"conv{ksize} {Ho}x{Wo} cin{cin}{'+' + str(cin2) if cin2 else ''} cout{cout} s{stride}{' up' if upsample_to else ''}"
+                  f"{' f32' if out_f32 else ''} n{n}"):
         ws = _workspace(x.device)
         if cs is None:
             L.call("mimo_conv2d", dt_code(x.dtype), x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr(),

@@ -73,3 +73,22 @@ def pack_proj_tail(weight, dtype):
     kidx = torch.tensor(ff2_kperm(), device=weight.device)
     w = weight.detach().float()[ridx].reshape(co, k // 32, 32)[:, :, kidx].reshape(co, k)
     return w.to(dtype).contiguous()
+
+
+def pack_rows_tail(weight, dtype):
+    """A [C, C] Linear weight whose operand arrives in natural K order (the attention to_out of mimo_block_tail_fused): rows in
+    the tile order of pack_proj_tail, K axis untouched."""
+    co, k = weight.shape
+    assert co % 64 == 0 and co // 2 % 32 == 0
+    half = co // 2
+    rows = []
+    for q in range(co // 64):
+        rows += list(range(32 * q, 32 * q + 32)) + list(range(half + 32 * q, half + 32 * q + 32))
+    return weight.detach().float()[torch.tensor(rows, device=weight.device)].to(dtype).contiguous()
+
+
+def pack_block_tail_stream(to_out_w, ff1_w_packed, proj_out_w, dtype):
+    """The weight stream of mimo_block_tail_fused, one [10 C, C] tensor in the order the kernel walks it: to_out (rows in tile
+    order) | the GEGLU-packed FF1 weight (pack_geglu) with its K axis permuted — its operand, the LayerNorm output, comes
+    straight from accumulator registers — | proj_out (pack_proj_tail)."""
+    return torch.cat([pack_rows_tail(to_out_w, dtype), pack_ff2_kperm(ff1_w_packed, dtype), pack_proj_tail(proj_out_w, dtype)], 0).contiguous()

@@ -620,3 +620,26 @@ def test_interpolate_latents_matches_reference():
     P.tensor_interpolation = None
     with pytest.raises(TypeError):
         P.interpolate_latents(lat, 2)
+
+
+def test_gelu_polynomial_constants():
+    """common.cuh's GELU: max(x, 0) - |x| 2^P(|x|) with P a degree-7 polynomial (the Gaussian tail's log2).  The constants are
+    read from the header and evaluated in float32 the way the kernel does (Horner, clamp at 6): absolute error against the
+    erf form of torch's F.gelu below 3.5e-7 over [-12, 12], zero at zero, identity for large x."""
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "mimo_amd", "csrc", "common.cuh")).read()
+    m = re.search(r"GELU_P\[8\] = \{([^}]*)\}", src)
+    assert m, "GELU_P not found"
+    c = np.array([float(v.strip().rstrip("f")) for v in m.group(1).split(",")], dtype=np.float32)
+    assert c.shape == (8,)
+    x = np.linspace(-12, 12, 1200001).astype(np.float32)
+    u = np.minimum(np.abs(x), np.float32(6.0))
+    p = np.full_like(u, c[7])
+    for k in range(6, -1, -1):
+        p = (p * u + c[k]).astype(np.float32)
+    g = (np.maximum(x, np.float32(0)) - u * np.exp2(p).astype(np.float32)).astype(np.float32)
+    xd = x.astype(np.float64)
+    ref = 0.5 * xd * (1 + erf(xd / np.sqrt(2)))
+    assert np.abs(g - ref).max() < 3.5e-7
+    assert abs(float(g[np.argmin(np.abs(x))])) < 1e-12 and abs(float(g[-1]) - 12.0) < 1e-6 and abs(float(g[0])) < 1e-7

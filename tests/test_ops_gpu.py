@@ -443,6 +443,77 @@ def test_ff_proj_fused_c320(dev, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,rows_per_img", [(128, 0), (8192 + 77, 1000), (33, 0), (40000, 4096 + 64), (1024, 128)])
+def test_block_tail_fused_c320(dev, dtype, M, rows_per_img):
+    """mimo_block_tail_fused (C = 320): attention output projection (+ per-image vector) + residual, LayerNorm, feed-forward,
+    proj_out + residual in one launch vs the four launches it replaces and a torch fp32 reference that rounds to half where
+    the kernel does (LayerNorm output, hidden activations, feed-forward result).  rows_per_img that do not divide the
+    128-row panel: a panel straddles two images."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_block_tail_stream, pack_ff2_kperm, pack_geglu
+    C = 320
+    o = rnd((M, C), dev, dtype, 1)
+    wo = rnd((C, C), dev, torch.float32, 10, C ** -0.5)
+    bo = rnd((C,), dev, torch.float32, 11, 0.1)
+    t = rnd((M, C), dev, torch.float32, 12) + 0.5   # a row mean away from zero
+    gamma = 1 + rnd((C,), dev, torch.float32, 13, 0.2)
+    beta = rnd((C,), dev, torch.float32, 14, 0.2)
+    w1 = rnd((8 * C, C), dev, torch.float32, 2, C ** -0.5)
+    b1 = rnd((8 * C,), dev, torch.float32, 3, 0.1)
+    w2 = rnd((C, 4 * C), dev, torch.float32, 4, (4 * C) ** -0.5)
+    b2 = rnd((C,), dev, torch.float32, 5, 0.1)
+    wp = rnd((C, C), dev, torch.float32, 7, C ** -0.5)
+    bp = rnd((C,), dev, torch.float32, 8, 0.1)
+    x = rnd((M, C), dev, torch.float32, 9)
+    ib = ibv = None
+    if rows_per_img:
+        nimg = (M + rows_per_img - 1) // rows_per_img
+        ib = rnd((nimg, 3 * C), dev, torch.float32, 15)[:, C:2 * C]   # a row-strided view, as the pipeline hands it over
+        ibv = ib[torch.arange(M, device=dev) // rows_per_img]
+    w1p, b1p = pack_geglu(w1, b1, dtype)
+    ws = pack_block_tail_stream(wo, w1p, wp, dtype)
+    out = ops.block_tail_fused(o, ws, bo, t, gamma, beta, 1e-5, b1p, pack_ff2_kperm(w2, dtype), b2, bp, x,
+                               img_bias=ib, rows_per_img=rows_per_img or 1)
+    assert out.shape == (M, C) and out.dtype == torch.float32
+    y = t + o.float() @ wo.to(dtype).float().t() + bo + (ibv if ibv is not None else 0)
+    n = F.layer_norm(y, (C,), gamma, beta, 1e-5).to(dtype).float()
+    hcat = n @ w1.to(dtype).float().t() + b1
+    hid = (hcat[:, :4 * C] * F.gelu(hcat[:, 4 * C:])).to(dtype).float()
+    z = (y + hid @ w2.to(dtype).float().t() + b2).to(dtype).float()
+    ref = x + z @ wp.to(dtype).float().t() + bp
+    # (a half rounding of n that lands on the other side of a tie moves a few elements: looser than the pure-fp32 bound)
+    assert rel_l2(out, ref) < OUT_TOL[dtype] / 2
+    yy, nn = ops.gemm(o, wo.to(dtype).contiguous(), bias=bo, img_bias=ib, rows_per_img=rows_per_img or 1, residual=t, out_f32=True,
+                      ln=dict(gamma=gamma, beta=beta, eps=1e-5))
+    zz = ops.gemm(ops.gemm(nn, w1p, bias=b1p, geglu=True), w2.to(dtype).contiguous(), bias=b2, residual=yy)
+    four = ops.gemm(zz, wp.to(dtype).contiguous(), bias=bp, residual=x, out_f32=True)
+    assert rel_l2(out, four) < OUT_TOL[dtype]
+    assert rel_l2(out[M // 2], ref[M // 2]) < OUT_TOL[dtype] and rel_l2(out[:, 161], ref[:, 161]) < OUT_TOL[dtype]
+    assert rel_l2(out[:, 7], ref[:, 7]) < OUT_TOL[dtype] and rel_l2(out[-1], ref[-1]) < OUT_TOL[dtype]
+
+
+def test_block_tail_fused_is_batch_invariant(dev):
+    """A sharded unit (one CFG half: b = 1) and the full b = 2 launch of the same window must produce the same bits: the
+    kernel's result for a row depends on that row, the weights and its image's vector only — not on the panel it falls into
+    or on the number of rows in the launch."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_block_tail_stream, pack_ff2_kperm, pack_geglu
+    dtype, C, rpi = torch.float16, 320, 4096 + 64   # (an image boundary in the middle of a 128-row panel of the full launch)
+    M = 2 * rpi
+    o = rnd((M, C), dev, dtype, 1)
+    t, x = rnd((M, C), dev, torch.float32, 12), rnd((M, C), dev, torch.float32, 9)
+    ib = rnd((2, C), dev, torch.float32, 15)
+    w1p, b1p = pack_geglu(rnd((8 * C, C), dev, torch.float32, 2, C ** -0.5), rnd((8 * C,), dev, torch.float32, 3, 0.1), dtype)
+    ws = pack_block_tail_stream(rnd((C, C), dev, torch.float32, 10, C ** -0.5), w1p, rnd((C, C), dev, torch.float32, 7, C ** -0.5), dtype)
+    w2k = pack_ff2_kperm(rnd((C, 4 * C), dev, torch.float32, 4, (4 * C) ** -0.5), dtype)
+    vec = [rnd((C,), dev, torch.float32, s, 0.1) for s in (11, 13, 14, 5, 8)]
+    run = lambda sl, ibs: ops.block_tail_fused(o[sl], ws, vec[0], t[sl], 1 + vec[1], vec[2], 1e-5, b1p, w2k, vec[3], vec[4], x[sl],
+                                               img_bias=ibs, rows_per_img=rpi)
+    full = run(slice(0, M), ib)
+    assert torch.equal(full[:rpi], run(slice(0, rpi), ib[:1])) and torch.equal(full[rpi:], run(slice(rpi, M), ib[1:]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,B,spike", [(64, 1, 0), (100, 3, 0), (1024, 2, 0), (333, 2, 5), (4096, 1, 0)])
 def test_attention_single_head_d512(dev, dtype, N, B, spike):
     """The VAE mid-block attention: ONE head of d = 512 over the N tokens of an image (attn512_kernel: head dimension split

@@ -46,10 +46,11 @@ def main():
     reader.update(writer)
     x = torch.randn(48, h, h, 8, generator=g).to(dev).to(dtype)
     pose = torch.randn(48, h, h, 320, generator=g).to(dev)
-    ops.EVENTS = []
+    ops.EVENTS, ops.TAGS = [], []
     unet.run_tokens(x, 499, ehs, 2, 24, pose)
     torch.cuda.synchronize()
     ev, ops.EVENTS = ops.EVENTS, None
+    tags, ops.TAGS = ops.TAGS, None
     t_gemm = sum(e0.elapsed_time(e1) for n, e0, e1, fl, nb in ev if n == "gemm_kernel") * 1e-3
     t_attn = sum(e0.elapsed_time(e1) for n, e0, e1, fl, nb in ev if n == "attn_kernel") * 1e-3
     b_gemm = sum(max(fl / MFMA_RATE, nb / HBM_RATE) for n, e0, e1, fl, nb in ev if n == "gemm_kernel")
@@ -62,6 +63,20 @@ def main():
           f"{HBM_RATE/1e12:.1f} TB/s; MFMA-only bound at {MFMA_RATE/1e15:.1f} PFLOP/s: {b_gemm_mfma*1e3:.2f} ms)")
     print(f"spatial attention at {ATTN_RATE/1e15:.1f} PFLOP/s: {b_attn*1e3:.2f} ms")
     print(f"bound of this op decomposition: {(b_gemm + b_attn + rest)*1e3:.2f} ms  (measured {t_fwd*1e3:.2f} ms = {t_fwd/(b_gemm + b_attn + rest):.2f} x)")
+    # per-shape table of the GEMM / conv launches, by time above their own ceiling
+    shapes = {}
+    for (n, e0, e1, fl, nb), tag in zip(ev, tags):
+        if n != "gemm_kernel":
+            continue
+        r = shapes.setdefault(tag, [0, 0.0, 0.0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+        r[2] += max(fl / MFMA_RATE, nb / HBM_RATE) * 1e3
+        r[3] += fl
+        r[4] += nb
+    print(f"{'shape':64s} {'n':>3s} {'ms':>7s} {'bound':>7s} {'excess':>7s} {'TFLOP/s':>8s} {'TB/s':>6s}")
+    for tag, (cnt, ms, bd, fl, nb) in sorted(shapes.items(), key=lambda kv: kv[1][2] - kv[1][1]):
+        print(f"{tag:64s} {cnt:3d} {ms:7.2f} {bd:7.2f} {ms - bd:7.2f} {fl / ms / 1e9:8.0f} {nb / ms / 1e9:6.2f}")
     reader.clear()
     writer.clear()
 
