@@ -643,3 +643,36 @@ def test_gelu_polynomial_constants():
     ref = 0.5 * xd * (1 + erf(xd / np.sqrt(2)))
     assert np.abs(g - ref).max() < 3.5e-7
     assert abs(float(g[np.argmin(np.abs(x))])) < 1e-12 and abs(float(g[-1]) - 12.0) < 1e-6 and abs(float(g[0])) < 1e-7
+
+
+def test_fused_block_weight_packings():
+    """The re-layouts of mimo_block_tail_fused's weights (mimo_amd.packing): pure permutations of the checkpoint tensors.
+    pack_ff2_kperm: position 8g + j of every 32-block holds original index 4g + j | 16 + 4g + (j - 4) — the order in which the
+    four lane groups of an MFMA accumulator tile pair hold a 32-column chunk; a product is unchanged when the operand is
+    permuted alike.  pack_proj_tail / pack_rows_tail: tile q = output columns 32q..32q+31 then 160+32q..; the stream is
+    to_out | FF1 | proj_out, 50 tiles of 64 rows."""
+    from mimo_amd.packing import ff2_kperm, pack_block_tail_stream, pack_ff2_kperm, pack_geglu, pack_proj_tail, pack_rows_tail
+    perm = ff2_kperm()
+    assert sorted(perm) == list(range(32))
+    for g in range(4):   # lane group g: columns 4g..4g+3 of the first 16-tile, then of the second
+        assert perm[8 * g:8 * g + 8] == [4 * g + r for r in range(4)] + [16 + 4 * g + r for r in range(4)]
+    C = 320
+    gen = torch.Generator().manual_seed(3)
+    w2 = torch.randn(C, 4 * C, generator=gen)
+    h = torch.randn(7, 4 * C, generator=gen)
+    idx = torch.tensor(perm)
+    hp = h.reshape(7, -1, 32)[:, :, idx].reshape(7, -1)
+    assert torch.allclose(hp @ pack_ff2_kperm(w2, torch.float32).t(), h @ w2.t(), atol=1e-4)
+    wp = torch.randn(C, C, generator=gen)
+    rows = pack_rows_tail(wp, torch.float32)
+    order = [r for q in range(5) for r in list(range(32 * q, 32 * q + 32)) + list(range(160 + 32 * q, 160 + 32 * q + 32))]
+    assert sorted(order) == list(range(C)) and torch.equal(rows, wp[order])
+    tail = pack_proj_tail(wp, torch.float32)
+    assert torch.equal(tail, wp[order].reshape(C, -1, 32)[:, :, idx].reshape(C, C))
+    w1, b1 = torch.randn(8 * C, C, generator=gen), torch.randn(8 * C, generator=gen)
+    w1p, b1p = pack_geglu(w1, b1, torch.float32)
+    # GEGLU packing: 16 value rows | 16 gate rows blocks
+    assert torch.equal(w1p[:16], w1[:16]) and torch.equal(w1p[16:32], w1[4 * C:4 * C + 16]) and torch.equal(b1p[32:48], b1[16:32])
+    ws = pack_block_tail_stream(wp, w1p, wp, torch.float32)
+    assert ws.shape == (10 * C, C) and ws.shape[0] == 50 * 64
+    assert torch.equal(ws[:C], rows) and torch.equal(ws[C:9 * C], pack_ff2_kperm(w1p, torch.float32)) and torch.equal(ws[9 * C:], tail)
