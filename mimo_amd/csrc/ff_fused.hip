@@ -1,6 +1,12 @@
-// ff_fused.hip — the GEGLU feed-forward of a transformer block as ONE kernel (gfx950), C = 320 (level 0 of the UNets):
+// ff_fused.hip — the tail of a transformer block as ONE kernel (gfx950), C = 320 (level 0 of the UNets).  Three entry points
+// share the kernel (template MODE):
 //
-//   out[M, C] = res[M, C] + GEGLU(A[M, C] @ W1^T + b1) @ W2^T + b2          (A = LayerNorm output, half; res fp32; out half)
+//   0  mimo_ff_fused         out[M, C] = res + GEGLU(A @ W1^T + b1) @ W2^T + b2                 (A = LayerNorm output; out half)
+//   1  mimo_ff_proj_fused    out32     = x + (res + FF(A)) @ Wp^T + bp                          (+ the owning transformer's proj_out)
+//   2  mimo_block_tail_fused y = res + O @ Wo^T + bo (+ img_bias);  n = LayerNorm(y);  out32 = x + (y + FF(n)) @ Wp^T + bp
+//                            (+ the attention's to_out, its residual, the collapsed cross-attention vector and the LayerNorm)
+//
+// The feed-forward core, which the other two wrap with projection steps on the same weight stream (see MODE below):
 //
 // replaces diffusers FeedForward(GEGLU, Linear) + the residual add of src/models/attention.py:428-429 /
 // motion_module.py:258 as two launches (mimo_gemm GEGLU, then mimo_gemm + residual) with the [M, 4C] intermediate
@@ -38,9 +44,9 @@ struct FFArgs {
   const float* b1;      // [8C] packed like W1
   const float* b2;      // [C]
   const float* res;     // fp32 [M, ldr]
-  uint16_t* out;        // half [M, ldo]                                         (TAIL = 0)
+  uint16_t* out;        // half [M, ldo]                                         (MODE 0)
   int64_t lda, ldr, ldo, M;
-  // TAIL = 1: the block's output projection folded in:  out32 = x + (res + FF(A)) @ Wp^T + bp
+  // MODE >= 1: the block's output projection folded in:  out32 = x + (res + FF(A)) @ Wp^T + bp
   const uint16_t* Wp;   // half [C, C]: rows in tile order (tile q = columns 32q..32q+31 | 160+32q..160+32q+31), K axis permuted
   const float* bp;      // [C]
   const float* x;       // fp32 [M, ldx]: the block input (the residual of proj_out)
