@@ -426,7 +426,11 @@ __global__ __launch_bounds__(256) void cast_kernel(const void* in, int f32, int6
 
 inline unsigned stream_grid(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
-  if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  // grid-stride over the rest; measured (tools/ln_micro.py --gn): the large tensors of levels 0 / 1 and of the VAE stream
+  // 8-9 % faster from 16384 blocks than from 2048, the small ones prefer the short grid
+  int64_t cap = work_items >= 6000000 ? 16384 : work_items >= 3000000 ? 4096 : 2048;
+  if (const int64_t forced = tune_env("MIMO_STREAM_BLOCKS", 0)) cap = forced;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
@@ -529,8 +533,16 @@ extern "C" int mimo_layer_norm(const void* x, int x_is_f32, int dtype, int64_t r
   if (!x || (!out && !out_f32) || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 2048) return MIMO_EINVAL;
   if (pe && (rows_per_frame <= 0 || pe_frames <= 0)) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  int64_t nb = (rows + 3) / 4;
-  if (nb > 256 * 8) nb = 256 * 8;  // persistent waves, grid-stride over rows
+  // Persistent waves, grid-stride over rows.  Few, long-lived waves win: a wave pays for its parameter loads and its first,
+  // unhidden row once, and the bytes in flight (two rows per wave) only have to cover latency x bandwidth.  Measured optimum
+  // (tools/ln_micro.py, profiles/r3_ln_grid_probe.txt): ~12 rows per wave, at most min(655360 / C, 1536) blocks — 12288 x 1280
+  // takes 25.5 us with 512 blocks against 43.6 us with the former 2048.
+  int64_t nb = (rows + 11) / 12;
+  int64_t cap = 655360 / C < 1536 ? 655360 / C : 1536;
+  if (const int64_t forced = tune_env("MIMO_LN_BLOCKS", 0)) nb = (rows + 3) / 4, cap = forced;
+  if (cap < 1) cap = 1;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
   const unsigned grid = (unsigned)nb;
   const int vpl = (C / 8 + 63) / 64;
 #define LN_LAUNCH(DT, V)                                                                              \
