@@ -9,7 +9,7 @@ import sys
 
 def family(k):
     k = re.sub(r"\(anonymous namespace\)::", "", k)
-    for name in ("gemm_stream_kernel", "gemm_dense_persist_kernel", "splitk_reduce_kernel", "attn40_kernel", "temporal_attn_kernel",
+    for name in ("ff_fused_kernel", "gemm_stream_kernel", "gemm_dense_persist_kernel", "splitk_reduce_kernel", "attn40_kernel", "temporal_attn_kernel",
                  "attn_kernel", "gn_apply_kernel", "gn_stats", "layer_norm_kernel"):
         if name in k:
             return name
@@ -27,6 +27,15 @@ def main(path):
         if f:
             tot[f][r["Counter_Name"]] += float(r["Counter_Value"])
             n[f].add(r["Dispatch_Id"])
+    extra = sorted({c for t in tot.values() for c in t} - {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                          "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"})
+    if extra:  # any other counters of the pass: per busy CU cycle
+        print(f"{'family':28s} {'dispatches':>10s} " + " ".join(f"{c[-22:]:>22s}" for c in extra) + "   (per SQ_BUSY_CU_CYCLES)")
+        for f, t in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CU_CYCLES", 0)):
+            b = t.get("SQ_BUSY_CU_CYCLES", 0) or float("nan")
+            print(f"{f:28s} {len(n[f]):10d} " + " ".join(f"{t.get(c, 0) / b:22.4f}" for c in extra))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in {c for t in tot.values() for c in t}:
+            return
     print(f"{'family':28s} {'dispatches':>10s} {'MFMA busy':>10s} {'active':>8s} {'parked':>8s} {'stalled':>8s}")
     for f, t in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CU_CYCLES", 0)):
         w = t.get("SQ_WAVE_CYCLES", 0) or 1
