@@ -414,6 +414,25 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 // ------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// V tile row placement.  A 32-lane group of ds_read_b64_tr_b16 gathers 8 kv rows x 32 B: rows r..r+3 and r+16..r+19 (the k-slot
+// order of the P operand).  Row-major at the 80-byte pitch of the lane-linear DMA image, rows k and 16 + k fall on the same
+// banks (16 x 80 = 5 x 256 B) and row 3 wraps onto row 0: every transposed read took >= 2 LDS cycles per group
+// (SQ_LDS_BANK_CONFLICT = 55 % of the kernel's LDS-array cycles, profiles/r3_pmc_lds_by_family_final.txt).  The 8 spans tile
+// the 256-byte bank window exactly when the rows sit in 8 slots of equal parity inside one 16-slot window (slot s starts at
+// 16-byte unit 5 s mod 16), so a tile row r goes to slot
+//     32 (r / 32) + 16 b8 + 8 b16 + 2 (r & 3) + b4        (b4, b8, b16 = bits 2, 3, 4 of r)
+// — a bit permutation, applied on the SOURCE row of the DMA lanes; the K tile keeps its order (its ds_read_b128 groups are
+// conflict-free at this pitch).
+#ifndef MIMO_ATTN40_VPERM
+#define MIMO_ATTN40_VPERM 1
+#endif
+__device__ __forceinline__ int v_slot_of_row(int r) {
+  return MIMO_ATTN40_VPERM ? (r & 32) | (((r >> 3) & 1) << 4) | (((r >> 4) & 1) << 3) | ((r & 3) << 1) | ((r >> 2) & 1) : r;
+}
+__device__ __forceinline__ int v_row_of_slot(int s) {
+  return MIMO_ATTN40_VPERM ? (s & 32) | (((s >> 3) & 1) << 4) | (((s >> 4) & 1) << 3) | ((s & 1) << 2) | ((s >> 1) & 3) : s;
+}
+
 // ABL (tune build only): 1 = no global traffic after the prologue (every tile recomputes on the first tiles' K / V):
 // the compute-only time of the loop; 2 = DMAs issued but never waited for (stale tiles): issue cost without wait cost
 // NW = waves per block (4 | 8): a block covers 64 NW queries.  The per-tile DMA work (10 instructions, ~100+ issue cycles
@@ -519,8 +538,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   }
   // byte offsets of this lane's chunks relative to the tile's first row, per segment (self | bank)
   const unsigned voffK[2] = {(unsigned)prow[0] * ldk1 + pcol[0], (unsigned)prow[0] * ldk2 + pcol[0]};
-  const unsigned voffV[2] = {(unsigned)prow[0] * ldv1 + pcol[0], (unsigned)prow[0] * ldv2 + pcol[0]};
-  const unsigned voff3[2] = {(unsigned)prow[1] * (v3 ? ldv1 : ldk1) + pcol[1], (unsigned)prow[1] * (v3 ? ldv2 : ldk2) + pcol[1]};
+  // (V: the LDS slot a lane fills holds tile row v_row_of_slot(slot))
+  const int vrow[2] = {v_row_of_slot(prow[0]), v_row_of_slot(prow[1])};
+  const unsigned voffV[2] = {(unsigned)vrow[0] * ldv1 + pcol[0], (unsigned)vrow[0] * ldv2 + pcol[0]};
+  const int row3 = v3 ? vrow[1] : prow[1];
+  const unsigned voff3[2] = {(unsigned)row3 * (v3 ? ldv1 : ldk1) + pcol[1], (unsigned)row3 * (v3 ? ldv2 : ldk2) + pcol[1]};
   const i32x4 rk1 = make_rsrc(kb0, (unsigned)((int64_t)a.Nk * ldk1)), rv1 = make_rsrc(vb0, (unsigned)((int64_t)a.Nk * ldv1));
   const i32x4 rk2 = make_rsrc(has2 ? a.k2 : kb0, has2 ? (unsigned)((int64_t)a.Nk2 * ldk2) : 0u);
   const i32x4 rv2 = make_rsrc(has2 ? a.v2 : vb0, has2 ? (unsigned)((int64_t)a.Nk2 * ldv2) : 0u);
@@ -538,8 +560,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     const unsigned soffk = (unsigned)kv0 * (s2 ? ldk2 : ldk1), soffv = (unsigned)kv0 * (s2 ? ldv2 : ldv1);
     unsigned oK = s2 ? voffK[1] : voffK[0], oV = s2 ? voffV[1] : voffV[0], o3 = s2 ? voff3[1] : voff3[0];
     if (kv0 + KV_TILE > nk) {  // ragged last tile of a segment: rows past the end read zeros
-      if (kv0 + prow[0] >= nk) oK = oV = OOBA;
-      if (kv0 + prow[1] >= nk) o3 = OOBA;
+      if (kv0 + prow[0] >= nk) oK = OOBA;
+      if (kv0 + vrow[0] >= nk) oV = OOBA;
+      if (kv0 + row3 >= nk) o3 = OOBA;
     }
     const unsigned dK = smem_base + (unsigned)(K_OFF + buf * TILEB), dV = smem_base + (unsigned)(V_OFF + buf * TILEB);
     if (NW == 4) {
@@ -569,11 +592,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     const unsigned ldkb = s2 ? ldk2 : ldk1, ldvb = s2 ? ldv2 : ldv1;
     const __amdgpu_buffer_rsrc_t bk = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? a.k2 : kb0), 0, (int)((int64_t)nk * ldkb), 0x00020000);
     const __amdgpu_buffer_rsrc_t bv = __builtin_amdgcn_make_buffer_rsrc((void*)(s2 ? a.v2 : vb0), 0, (int)((int64_t)nk * ldvb), 0x00020000);
-    const bool ok0 = kv0 + srow0 < nk, ok2 = kv0 + srow2 < nk;
+    const int vr0 = v_row_of_slot(srow0), vr2 = v_row_of_slot(srow2);
+    const bool ok0 = kv0 + srow0 < nk, ok2 = kv0 + srow2 < nk, okv0 = kv0 + vr0 < nk, okv2 = kv0 + vr2 < nk;
     sreg[0] = __builtin_amdgcn_raw_buffer_load_b128(bk, ok0 ? (unsigned)srow0 * ldkb + scol0 : OOBA, (unsigned)kv0 * ldkb, 0);
-    sreg[1] = __builtin_amdgcn_raw_buffer_load_b128(bv, ok0 ? (unsigned)srow0 * ldvb + scol0 : OOBA, (unsigned)kv0 * ldvb, 0);
+    sreg[1] = __builtin_amdgcn_raw_buffer_load_b128(bv, okv0 ? (unsigned)vr0 * ldvb + scol0 : OOBA, (unsigned)kv0 * ldvb, 0);
     if (s3) {
-      if (s3v) sreg[2] = __builtin_amdgcn_raw_buffer_load_b128(bv, ok2 ? (unsigned)srow2 * ldvb + scol2 : OOBA, (unsigned)kv0 * ldvb, 0);
+      if (s3v) sreg[2] = __builtin_amdgcn_raw_buffer_load_b128(bv, okv2 ? (unsigned)vr2 * ldvb + scol2 : OOBA, (unsigned)kv0 * ldvb, 0);
       else sreg[2] = __builtin_amdgcn_raw_buffer_load_b128(bk, ok2 ? (unsigned)srow2 * ldkb + scol2 : OOBA, (unsigned)kv0 * ldkb, 0);
     }
   };
@@ -594,7 +618,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   // {0, 16, 4, 20}[g] + (m >> 2), d = 16 dt + 4 (m & 3) ..; the hardware hands lane i the column d = 16 dt + i of those
   // 4 kv rows.  For dt = 2 the chunks m & 3 = 2, 3 (d = 40..47) are the constant ones-row / zero slots.
   const int kvb = 16 * (g & 1) + 4 * (g >> 1);
-  const unsigned vaddr = smem_base + (unsigned)(V_OFF + (kvb + (i16 >> 2)) * ROWB + 8 * (i16 & 3));
+  const unsigned vaddr = smem_base + (unsigned)(V_OFF + v_slot_of_row(kvb + (i16 >> 2)) * ROWB + 8 * (i16 & 3));
+  constexpr int HI = MIMO_ATTN40_VPERM ? 16 : 8;   // slot distance of tile rows r and r + 8
   const bool vconst = (i16 & 3) >= 2;
   const unsigned vaddr2 = vconst ? smem_base + (unsigned)(CONST_OFF + 16 + 8 * ((i16 & 3) - 2)) : vaddr + 64;
   const unsigned vstep2 = vconst ? 0u : 1u;
@@ -722,13 +747,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         MIMO_TR(vlo[0][u], vaddr, RD * TILEB + 32 * u * ROWB);
-        MIMO_TR(vhi[0][u], vaddr, RD * TILEB + (32 * u + 8) * ROWB);
+        MIMO_TR(vhi[0][u], vaddr, RD * TILEB + (32 * u + HI) * ROWB);
         MIMO_TR(vlo[1][u], vaddr, RD * TILEB + 32 * u * ROWB + 32);
-        MIMO_TR(vhi[1][u], vaddr, RD * TILEB + (32 * u + 8) * ROWB + 32);
+        MIMO_TR(vhi[1][u], vaddr, RD * TILEB + (32 * u + HI) * ROWB + 32);
       }
       // dt = 2: lanes of the constant chunks must not move with u / hi: their offsets are applied through vstep2
       {
-        const unsigned a00 = va2, a01 = va2 + (8 * ROWB) * vstep2, a10 = va2 + (32 * ROWB) * vstep2, a11 = va2 + (40 * ROWB) * vstep2;
+        const unsigned a00 = va2, a01 = va2 + (HI * ROWB) * vstep2, a10 = va2 + (32 * ROWB) * vstep2, a11 = va2 + ((32 + HI) * ROWB) * vstep2;
         MIMO_TR(vlo[2][0], a00, 0);
         MIMO_TR(vhi[2][0], a01, 0);
         MIMO_TR(vlo[2][1], a10, 0);
