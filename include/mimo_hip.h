@@ -177,6 +177,45 @@ int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);
+/* GroupNorm folded to a per-(image, channel) affine: ab fp32 [n][2][C], ab[i][0][c] = rstd(i, g(c)) * gamma[c],
+ * ab[i][1][c] = beta[c] - mean(i, g(c)) * ab[i][0][c], so that GroupNorm(x)[c] = x * a + b.  The operand of
+ * mimo_conv3x3_fused (the apply pass of src/models/resnet.py:20-28,220-221,237 without a pass over the tensor). */
+int mimo_group_norm_affine(const float* stats, const float* gamma, const float* beta, int n, int C, int groups,
+                           float* ab, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * mimo_conv3x3_fused: 3x3 / stride 1 / pad 1 convolution that normalises its own input.
+ *   out = epilogue( conv3x3( silu?( x * a + b ) ) ),   x = the fp32 virtual channel concat [x1 | x2]
+ *   replaces, in ONE launch, the GroupNorm-apply (+ SiLU) pass AND the convolution it feeds:
+ *     ResnetBlock3D norm1 -> nonlinearity -> conv1 (+ time_emb_proj add)          src/models/resnet.py:217-229
+ *     ResnetBlock3D norm2 -> nonlinearity -> conv2 (+ residual, / output_scale)   src/models/resnet.py:231-247
+ *     diffusers ResnetBlock2D of the VAE Encoder / Decoder (AutoencoderKL, pipeline_...roiclip.py:120,430,438)
+ *     Upsample3D / Upsample2D: nearest x2 -> conv (upsample2x = 1, ab = NULL: plain cast)   src/models/resnet.py:31-76
+ *   x1: fp32 [n, Hs, Ws, C1], x2: fp32 [n, Hs, Ws, C2] or NULL (C2 = 0); (Hs, Ws) = (H, W), or (H/2, W/2) with upsample2x.
+ *       (C1 + C2) % 32 == 0; with x2: C1 % 64 == 0.  Only fp32 inputs: the residual stream is fp32.
+ *   ab: fp32 [n][2][C] from mimo_group_norm_affine, or NULL (no normalisation); silu: apply SiLU after the affine.
+ *   W:  half16 [Cout][ldw], K index = (ky*3 + kx) * C + c (the mimo_conv2d packing; ldw >= 9 C, extra columns —
+ *       a fused shortcut segment — are ignored).
+ *   out: fp32 [n, H, W, Cout]; H % 16 == 0, W % 16 == 0 (a block owns a 16 x 16 pixel tile + halo).
+ *   raw_out (nullable, not with upsample2x): half16 [n, H, W, C] plain cast of x, written as a side effect (it feeds
+ *       the fused 1x1 shortcut of the block's second convolution through mimo_conv2d's in2).
+ *   epilogue: bias [Cout], img_bias row = image / imgs_per_bias_row (the time embedding), MIMO_EPI_SILU,
+ *       residual fp32 [n, H, W, Cout], out_scale.  flags must contain MIMO_EPI_OUT_F32 (and MIMO_EPI_RES_F32 with a
+ *       residual).  Returns MIMO_EINVAL for shapes it does not cover (the caller then takes the two-launch path);
+ *       with ab: C <= 960 when Cout % 320 == 0, C <= 2560 otherwise (the affine table lives in LDS).
+ *   The summation order of an output element depends on the layer only, never on n.
+ * --------------------------------------------------------------------------------- */
+typedef struct mimo_hconv_params {
+  int n, H, W, Cout;
+  int upsample2x;        /* 0 | 1 */
+  int imgs_per_bias_row; /* 0 -> 1 */
+  int img_bias_ld;       /* row pitch of img_bias in floats; 0 -> Cout */
+} mimo_hconv_params;
+
+int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const float* x2, int C2, const float* ab, int silu,
+                       const void* W, int64_t ldw, float* out, const mimo_hconv_params* p, const float* bias,
+                       const float* img_bias, const float* residual, void* raw_out, float out_scale,
+                       unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * LayerNorm over the last dim of x [rows, C] (fp32 or half16) -> half16 `out` and / or fp32 `out_f32`, optional

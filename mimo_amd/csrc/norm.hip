@@ -313,6 +313,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, int C1, c
   }
 }
 
+// GroupNorm folded to y = x * a + b per (image, channel): the operand of mimo_conv3x3_fused (hconv.hip)
+__global__ __launch_bounds__(256) void gn_affine_kernel(const float* stats, const float* gamma, const float* beta, int n, int C,
+                                                        int groups, float* ab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * C) return;
+  const int img = i / C, c = i - img * C;
+  const int grp = c / (C / groups);
+  const float mean = stats[((int64_t)img * groups + grp) * 2], rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
+  const float a = rstd * gamma[c];
+  ab[(int64_t)img * 2 * C + c] = a;
+  ab[(int64_t)img * 2 * C + C + c] = fmaf(-mean, a, beta[c]);
+}
+
 // ---------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (C <= 64*8*4 = 2048).
 // ---------------------------------------------------------------------------------
@@ -523,6 +536,15 @@ extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int
     hipLaunchKernelGGL(gn_apply_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, (uint16_t*)raw_out);
   else
     return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_group_norm_affine(const float* stats, const float* gamma, const float* beta, int n, int C, int groups,
+                                      float* ab, void* stream) {
+  if (!stats || !gamma || !beta || !ab || n <= 0 || C <= 0 || groups <= 0 || C % groups) return MIMO_EINVAL;
+  hipLaunchKernelGGL(gn_affine_kernel, dim3((unsigned)((n * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta,
+                     n, C, groups, ab);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }

@@ -30,6 +30,10 @@ class EpilogueExt(ctypes.Structure):  # mimo_epilogue_ext
                 ("ln_eps", c_f), ("ln_pe_frames", c_i), ("ln_rows_per_frame", c_i64)]
 
 
+class HconvParams(ctypes.Structure):  # mimo_hconv_params
+    _fields_ = [(n, c_i) for n in ("n", "H", "W", "Cout", "upsample2x", "imgs_per_bias_row", "img_bias_ld")]
+
+
 class CompositeParams(ctypes.Structure):  # mimo_composite_params
     _fields_ = [("crop", c_vp), ("mask", c_vp), ("bk", c_vp), ("occ", c_vp), ("vid", c_vp), ("prev", c_vp), ("out", c_vp),
                 ("factor", ctypes.c_double)] + [(n, c_i) for n in ("pad_h", "pad_w", "top", "bottom", "left", "right",
@@ -51,6 +55,9 @@ SIGNATURES = {
     "mimo_group_norm_stats_cols": [c_vp, c_i, c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
+    "mimo_group_norm_affine": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
+    "mimo_conv3x3_fused": [c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i64, c_vp, ctypes.POINTER(HconvParams), c_vp, c_vp, c_vp,
+                           c_vp, c_f, c_u, c_vp],
     "mimo_layer_norm": [c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp],
     "mimo_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],

@@ -161,14 +161,45 @@ class ResnetBlock(HipModule):
                     g2=_f32(self.norm2.weight), be2=_f32(self.norm2.bias))
 
     def run(self, ctx, x, skip=None):
-        """x: fp32 [n,H,W,C1]; skip: fp32 [n,H,W,C2] concatenated virtually on the channel axis."""
+        """x: fp32 [n,H,W,C1]; skip: fp32 [n,H,W,C2] concatenated virtually on the channel axis.
+
+        Each of the two norm -> SiLU -> conv3x3 stages is ONE launch where mimo_conv3x3_fused covers the layer (the large
+        images: ops.hconv_supported, a function of the layer only): the convolution reads the fp32 tensor and applies the
+        GroupNorm affine + SiLU on its LDS tile.  Elsewhere: GroupNorm-apply pass -> half tensor -> implicit-GEMM conv."""
         p = self.packed(ctx.dtype)
         fused_sc = self.conv_shortcut is not None
-        if skip is None and self.time_emb_proj is None and banded(ctx, x.shape[1], x.shape[2]):
-            n, H, W, _ = x.shape
+        n, H, W, _ = x.shape
+        cout = self.out_channels
+        band = skip is None and self.time_emb_proj is None and banded(ctx, H, W)
+        tb = None
+        if self.time_emb_proj is not None:
+            s, e = self.temb_slice
+            tb = ctx.temb[:, s:e]
+        raw = None
+        # ---- norm1 -> SiLU -> conv1 (+ time embedding) ----
+        if ops.hconv_supported(x, cout, x2=skip):
+            st1 = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, x2=skip, dtype=ctx.dtype)
+            ab1 = ops.group_norm_affine(st1, p["g1"], p["be1"], self.in_channels, self.groups)
+            # the half cast of the raw input (operand of the fused shortcut in conv2) leaves as a side output
+            r = ops.conv3x3_fused(x, p["w1"], cout, x2=skip, ab=ab1, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
+                                  want_raw=fused_sc and not band, raw_dtype=ctx.dtype)
+            h, raw = r if (fused_sc and not band) else (r, None)
+        elif band:
             st1 = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
-            h = torch.empty((n, H, W, self.out_channels), device=x.device, dtype=torch.float32)
-            gn_conv3x3_banded(ctx, x, st1, p["g1"], p["be1"], self.groups, p["w1"], self.out_channels, p["b1"], h)
+            h = torch.empty((n, H, W, cout), device=x.device, dtype=torch.float32)
+            gn_conv3x3_banded(ctx, x, st1, p["g1"], p["be1"], self.groups, p["w1"], cout, p["b1"], h)
+        else:
+            a1, raw = ops.group_norm(x, p["g1"], p["be1"], groups=self.groups, eps=self.eps, silu=True, x2=skip,
+                                     dtype=ctx.dtype, want_raw=fused_sc)
+            # colstats=True: the conv epilogue also emits the GroupNorm column statistics of its output, so the norm
+            # that consumes it (norm2 here; the next block's norm for the block output) makes no statistics pass over HBM
+            h = ops.conv2d(a1, p["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True, colstats=True)
+        # ---- norm2 -> SiLU -> conv2 (+ shortcut | residual) ----
+        if not fused_sc and ops.hconv_supported(h, cout):
+            st2 = ops.group_norm_stats(h, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
+            ab2 = ops.group_norm_affine(st2, p["g2"], p["be2"], cout, self.groups)
+            return ops.conv3x3_fused(h, p["w2"], cout, ab=ab2, bias=p["b2"], residual=x, out_scale=1.0 / self.output_scale_factor)
+        if band:
             st2 = ops.group_norm_stats(h, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
             out = torch.empty_like(h)
             # conv2 reads GN2(h) per band; the fused shortcut segment reads half(x), the plain residual reads x
@@ -178,25 +209,15 @@ class ResnetBlock(HipModule):
                         lo, hi = max(0, y0 - 1), min(H, y1 + 1)
                         a2, _ = ops.group_norm_apply(h[i:i + 1, lo:hi], st2[i:i + 1], p["g2"], p["be2"], groups=self.groups,
                                                      silu=True, dtype=ctx.dtype)
-                        raw = None
+                        rawb = None
                         if fused_sc:
-                            _, raw = ops.group_norm_apply(x[i:i + 1, y0:y1], None, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
-                        ops.conv2d(a2, p["w2"], self.out_channels, pad=(1 if y0 == 0 else 0, 1), out_hw=(y1 - y0, W), x2=raw,
+                            _, rawb = ops.group_norm_apply(x[i:i + 1, y0:y1], None, None, None, dtype=ctx.dtype, want_norm=False, want_raw=True)
+                        ops.conv2d(a2, p["w2"], cout, pad=(1 if y0 == 0 else 0, 1), out_hw=(y1 - y0, W), x2=rawb,
                                    bias=p["b2"], residual=None if fused_sc else x[i:i + 1, y0:y1], out_f32=True,
                                    out_scale=1.0 / self.output_scale_factor, out=out[i:i + 1, y0:y1])
             return out
-        a1, raw = ops.group_norm(x, p["g1"], p["be1"], groups=self.groups, eps=self.eps, silu=True, x2=skip,
-                                 dtype=ctx.dtype, want_raw=fused_sc)
-        tb = None
-        if self.time_emb_proj is not None:
-            s, e = self.temb_slice
-            tb = ctx.temb[:, s:e]
-        # colstats=True: the conv epilogue also emits the GroupNorm column statistics of its output, so the norm
-        # that consumes it (norm2 here; the next block's norm for the block output) makes no statistics pass over HBM
-        h = ops.conv2d(a1, p["w1"], self.out_channels, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
-                       out_f32=True, colstats=True)
         a2, _ = ops.group_norm(h, p["g2"], p["be2"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
-        return ops.conv2d(a2, p["w2"], self.out_channels, x2=raw, bias=p["b2"],
+        return ops.conv2d(a2, p["w2"], cout, x2=raw, bias=p["b2"],
                           residual=None if fused_sc else x, out_f32=True,
                           out_scale=1.0 / self.output_scale_factor, colstats=True)
 
@@ -235,6 +256,9 @@ class Upsample(HipModule):
     def run(self, ctx, x, output_size=None):
         p = self.packed(ctx.dtype)
         n, H, W, _ = x.shape
+        if output_size is None and ops.hconv_supported(x, self.conv.out_channels, normed=False, upsample2x=True):
+            # the convolution gathers the nearest-x2 image from the fp32 source itself: no cast pass, no half intermediate
+            return ops.conv3x3_fused(x, p["w"], self.conv.out_channels, bias=p["b"], upsample2x=True)
         if output_size is None and banded(ctx, 2 * H, 2 * W):
             # row bands of the UPSAMPLED image (even boundaries): output rows [y0, y1) read virtual rows y0 - 1 .. y1, i.e.
             # source rows y0 / 2 - 1 .. y1 / 2; the band's virtual image starts at source row lo, so the first virtual row

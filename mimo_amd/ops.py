@@ -447,6 +447,85 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
                             want_norm=want_norm)
 
 
+def group_norm_affine(stats, gamma, beta, C, groups=32):
+    """GroupNorm folded to a per-(image, channel) affine: fp32 [n, 2, C] with GroupNorm(x)[c] = x * ab[i, 0, c] + ab[i, 1, c]
+    (the operand of conv3x3_fused)."""
+    _chk(stats, "stats")
+    n = stats.shape[0]
+    assert stats.shape == (n, groups, 2) and stats.is_contiguous() and gamma.numel() == C and beta.numel() == C
+    ab = torch.empty((n, 2, C), device=stats.device, dtype=torch.float32)
+    L.call("mimo_group_norm_affine", stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, C, groups, ab.data_ptr(), _stream())
+    return ab
+
+
+# Halo-tiled 3x3 convolution that normalises its own input (mimo_conv3x3_fused, csrc/hconv.hip).  Which layers take it
+# is a function of the LAYER (image size, channel counts) only, never of the number of images in the launch: a frame's
+# bits must not depend on the batch it is computed in.  Below HCONV_MIN_HW pixels per image the 16 x 16 pixel tiles
+# quantise worse than the row-tiled kernel's 192-row tiles (32 x 32 x 48 images x 640 channels = 384 blocks on 256 CUs).
+HCONV = True
+HCONV_MIN_HW = 4096
+
+
+def hconv_supported(x1, cout, *, x2=None, normed=True, upsample2x=False):
+    """True when conv3x3_fused covers this layer (see include/mimo_hip.h: mimo_conv3x3_fused)."""
+    if not HCONV or x1.dtype != torch.float32 or x1.dim() != 4 or (x2 is not None and x2.dtype != torch.float32):
+        return False
+    n, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    H, W = (2 * Hs, 2 * Ws) if upsample2x else (Hs, Ws)
+    C = C1 + C2
+    if H % 16 or W % 16 or H * W < HCONV_MIN_HW or C % 32 or (C2 and (C1 % 64 or C2 % 32)):
+        return False
+    if cout % 128 and cout % 320:
+        return False
+    if normed and C > (960 if cout % 320 == 0 else 2560):
+        return False
+    per_img = max(Hs * Ws * max(C1, C2) * 4, H * W * C * 2, (15 * W + 16) * cout * 4)
+    return per_img < 2 ** 31 and Hs * Ws < 2 ** 21
+
+
+def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, imgs_per_bias_row=1, residual=None,
+                  out_scale=1.0, upsample2x=False, want_raw=False, raw_dtype=None, out=None):
+    """fp32 [n, H, W, cout] = epilogue(conv3x3(silu(x * a + b))) in ONE launch: x = fp32 virtual concat [x1 | x2], ab from
+    group_norm_affine (None: plain cast, no SiLU — the up-sampling convolution); w = the packed weight of conv2d
+    (columns beyond 9 C, a fused shortcut segment, are ignored).  want_raw: also returns the half cast of x."""
+    _chk(x1, "x1")
+    assert x1.dim() == 4 and x1.is_contiguous() and x1.dtype == torch.float32 and w.is_contiguous()
+    n, Hs, Ws, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.dtype == torch.float32 and x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[3]
+    C = C1 + C2
+    H, W = (2 * Hs, 2 * Ws) if upsample2x else (Hs, Ws)
+    assert w.shape[0] == cout and w.shape[1] >= 9 * C, (w.shape, cout, C)
+    if ab is not None:
+        assert ab.shape == (n, 2, C) and ab.is_contiguous() and ab.dtype == torch.float32
+    if out is None:
+        out = torch.empty((n, H, W, cout), device=x1.device, dtype=torch.float32)
+    else:
+        assert out.shape == (n, H, W, cout) and out.is_contiguous() and out.dtype == torch.float32
+    raw = torch.empty((n, H, W, C), device=x1.device, dtype=raw_dtype or w.dtype) if want_raw else None
+    flags = L.EPI_OUT_F32
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == out.shape and residual.dtype == torch.float32
+        flags |= L.EPI_RES_F32
+    ldib = 0
+    if img_bias is not None:
+        assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
+        ldib = img_bias.stride(0)
+    p = L.HconvParams(n, H, W, cout, int(upsample2x), imgs_per_bias_row, ldib)
+    fl = 2 * n * H * W * cout * 9 * C
+    _count(fl)
+    with _Bracket("gemm_kernel", fl, _nbytes(x1, x2, out, residual, raw) + cout * 9 * C * w.element_size(),
+                  f"hconv {H}x{W} cin{C1}{'+' + str(C2) if C2 else ''} cout{cout}{' up' if upsample2x else ''}"
+                  f"{' gn' if ab is not None else ''}{' raw' if want_raw else ''} n{n}"):
+        L.call("mimo_conv3x3_fused", dt_code(w.dtype), x1.data_ptr(), C1, _ptr(x2), C2, _ptr(ab), int(ab is not None),
+               w.data_ptr(), w.shape[1], out.data_ptr(), ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), _ptr(raw),
+               float(out_scale), flags, _stream())
+    return (out, raw) if want_raw else out
+
+
 def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0, out_f32=False):
     """LayerNorm over the last dim of x [rows, C] -> half (fp32 if out_f32); optional + pe[(row // rows_per_frame) % pe_frames]."""
     _chk(x, "x")

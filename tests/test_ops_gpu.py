@@ -183,6 +183,97 @@ def test_conv2d_resblock_epilogue_and_fused_shortcut(dev, dtype):
     assert rel_l2(out.float(), F.silu(torch_conv_ref(h, w, b, 3, 1, None, None, None))) < OUT_TOL[dtype]
 
 
+HCONV_CASES = [
+    # n, H, W, C1, C2, Cout, gn, upsample2x
+    (2, 16, 16, 64, 0, 128, True, False),      # one tile per image: every border is padding; BN = 128 configuration
+    (3, 32, 48, 192, 0, 320, True, False),     # 3 chunks (odd count: the weight ring parity runs through), BN = 320
+    (2, 48, 32, 64, 32, 256, True, False),     # virtual concat, 1.5 chunks (the last sub-chunk is empty), BN = 256
+    (1, 64, 64, 320, 640, 320, True, False),   # an up-block conv1 of the 64 x 64 level (960 channels = the LDS table limit)
+    (2, 16, 32, 128, 0, 640, True, False),     # two channel tiles of 320
+    (2, 16, 16, 64, 0, 128, False, True),      # nearest x2 then conv, plain cast (Upsample3D)
+    (1, 32, 32, 640, 0, 640, False, True),
+]
+
+
+def hconv_ref(x1, x2, ab, w, dtype, ups):
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    y = x
+    if ab is not None:
+        y = F.silu(x * ab[:, 0][:, None, None, :] + ab[:, 1][:, None, None, :])
+    yt = y.to(dtype).float().permute(0, 3, 1, 2)
+    if ups:
+        yt = F.interpolate(yt, scale_factor=2, mode="nearest")
+    return F.conv2d(yt, w.float(), padding=1).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", HCONV_CASES)
+def test_conv3x3_fused_groupnorm_silu(dev, dtype, case):
+    """mimo_conv3x3_fused (halo-tiled conv that applies GroupNorm-affine + SiLU to its own fp32 input) vs torch: the reference
+    rounds the normalised activation to half exactly where the kernel does, so only the hardware exp / rcp of the SiLU
+    (a few half roundings flip) and the accumulation order differ."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv
+    n, H, W, C1, C2, cout, gn, ups = case
+    C = C1 + C2
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x1 = rnd((n, Hs, Ws, C1), dev, torch.float32, 1, 2.0) + 0.3
+    x2 = rnd((n, Hs, Ws, C2), dev, torch.float32, 2, 0.7) if C2 else None
+    w = rnd((cout, C, 3, 3), dev, dtype, 3, (9 * C) ** -0.5)
+    ws = rnd((cout, 96, 1, 1), dev, dtype, 9, 0.1)  # a fused-shortcut segment behind the 9 taps must be ignored
+    b = rnd((cout,), dev, torch.float32, 4)
+    temb = rnd((n, cout), dev, torch.float32, 5)
+    res = rnd((n, H, W, cout), dev, torch.float32, 6)
+    ab = None
+    if gn:
+        gamma, beta = rnd((C,), dev, torch.float32, 7) * 0.5 + 1.0, rnd((C,), dev, torch.float32, 8, 0.3)
+        stats = ops.group_norm_stats(x1, groups=32, eps=1e-5, x2=x2, dtype=dtype)
+        ab = ops.group_norm_affine(stats, gamma, beta, C, groups=32)
+        xc = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        gn_ref = F.group_norm(xc.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5).permute(0, 2, 3, 1)
+        aff = xc * ab[:, 0][:, None, None, :] + ab[:, 1][:, None, None, :]
+        assert rel_l2(aff, gn_ref) < 1e-5
+    ref0 = hconv_ref(x1, x2, ab, w, dtype, ups)
+    tol = 2e-4
+    out = ops.conv3x3_fused(x1, pack_conv(w, dtype), cout, x2=x2, ab=ab, upsample2x=ups)
+    assert out.shape == ref0.shape and out.dtype == torch.float32
+    assert rel_l2(out, ref0) < tol
+    wp = pack_conv(w, dtype, shortcut=ws)
+    want_raw = gn and not ups
+    r = ops.conv3x3_fused(x1, wp, cout, x2=x2, ab=ab, bias=b, img_bias=temb, residual=res, out_scale=0.5, upsample2x=ups,
+                          want_raw=want_raw)
+    out2, raw = r if want_raw else (r, None)
+    assert rel_l2(out2, 0.5 * (ref0 + b + temb[:, None, None, :] + res)) < tol
+    if want_raw:
+        xc = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        assert torch.equal(raw, xc.to(dtype))
+    # a per-batch-element bias row shared by groups of images; one image alone gives the bits it has inside the batch
+    if n % 2 == 0 or n == 1:
+        g = 2 if n % 2 == 0 else 1
+        out3 = ops.conv3x3_fused(x1, wp, cout, x2=x2, ab=ab, img_bias=temb[: n // g], imgs_per_bias_row=g, upsample2x=ups)
+        assert rel_l2(out3, ref0 + temb[: n // g].repeat_interleave(g, 0)[:, None, None, :]) < tol
+    one = ops.conv3x3_fused(x1[-1:].contiguous(), pack_conv(w, dtype), cout, x2=None if x2 is None else x2[-1:].contiguous(),
+                            ab=None if ab is None else ab[-1:].contiguous(), upsample2x=ups)
+    assert torch.equal(one, out[-1:])
+
+
+def test_conv3x3_fused_rejects_what_it_does_not_cover(dev):
+    from mimo_amd import lib as L, ops
+    from mimo_amd.packing import pack_conv
+    w = pack_conv(rnd((128, 64, 3, 3), dev, torch.float16, 1), torch.float16)
+    ok = torch.zeros((1, 16, 16, 64), device=dev)
+    assert ops.hconv_supported(torch.zeros((1, 64, 64, 64), device=dev), 128)
+    assert not ops.hconv_supported(torch.zeros((1, 98, 98, 64), device=dev), 128)      # not a multiple of the 16 x 16 tile
+    assert not ops.hconv_supported(torch.zeros((1, 64, 64, 160), device=dev), 160)     # channel counts of the half-width test models
+    assert not ops.hconv_supported(torch.zeros((1, 32, 32, 640), device=dev), 640)     # below HCONV_MIN_HW: the row-tiled kernel quantises better
+    assert not ops.hconv_supported(torch.zeros((1, 64, 64, 1920), device=dev), 320)    # affine table beyond the LDS budget
+    with pytest.raises(L.MimoHipError):
+        ops.conv3x3_fused(torch.zeros((1, 24, 16, 64), device=dev), w, 128)
+    with pytest.raises(L.MimoHipError):
+        ops.conv3x3_fused(ok, pack_conv(rnd((96, 64, 3, 3), dev, torch.float16, 2), torch.float16), 96)
+    ops.conv3x3_fused(ok, w, 128)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_split_k_long_reduction_few_tiles(dev, dtype):
     """Few output tiles + long K (the 8x8-level ResBlock convs, M = 48*64, K = 9*1280+640) take the split-K route:
