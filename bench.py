@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--shard-windows", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="with --shard-windows under torchrun at world size 1: take the sharded (RCCL) code path anyway")
     ap.add_argument("--graphs", action="store_true", help="replay the denoising forward as a captured hipGraph "
                     "(measured neutral: the launch queue never runs dry, so eager launches are the default)")
     ap.add_argument("--window-streams", type=int, default=None, help="HIP streams for the independent windows of a step "
@@ -358,7 +360,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: mimo_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment) the RCCL process group is created at
+    # ANY world size, so that `torchrun --nproc-per-node 1 bench.py --gpus 1` runs the barrier, the max-over-ranks
+    # all_reduce and (with --shard-windows --force-shard) the long-clip exchange on RCCL on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -367,7 +373,8 @@ def main():
     from mimo_amd import ops
     pipe = build_pipeline(dev, dtype)
     frames = a.frames * (world if a.shard_windows else 1)
-    pipe.shard_windows = a.shard_windows and world > 1
+    pipe.shard_windows = a.shard_windows and (world > 1 or (a.force_shard and use_dist))
+    pipe.shard_force = bool(a.force_shard)
     pipe.use_graphs = a.graphs and not pipe.shard_windows
     if a.window_streams is not None:
         pipe.window_streams = a.window_streams
@@ -388,7 +395,7 @@ def main():
         return video
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -408,7 +415,7 @@ def main():
         video = clip()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -26,6 +26,24 @@
 // the DMA queue before LDS reads it cannot prove independent.
 #include "common.cuh"
 
+// Compile-time experiment knobs (tools/hconv_variants.py builds one small library per setting and times them interleaved
+// in one process; the shipped library is built with the defaults below).
+#ifndef HCONV_LATE_CONSUME   // 1: waves 4-7 transform their patch pass AFTER the second half of a step (their SIMD partners
+#define HCONV_LATE_CONSUME 0 //    0-3 do it between the halves): the two VALU phases of a SIMD do not coincide
+#endif
+#ifndef HCONV_FENCE          // 1: sched_barrier fences around the patch work (keeps fragment live ranges inside a half)
+#define HCONV_FENCE 1
+#endif
+#ifndef HCONV_SETPRIO        // 1: s_setprio 1 around every MFMA cluster
+#define HCONV_SETPRIO 0
+#endif
+#ifndef HCONV_PRO            // 1: prologue with the first weight tile in flight beside the first patch passes (one barrier less)
+#define HCONV_PRO 1
+#endif
+#ifndef HCONV_ABLATE         // timing experiments (results are wrong): 1 no patch VALU, 2 no MFMA, 4 no weight DMA, 8 no patch DMA
+#define HCONV_ABLATE 0
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -137,11 +155,21 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
   const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
 
   // One DMA = 64 lanes x 16 B; lane l lands at lds_base + 16 l.  Inline asm: hipcc must not track it.
+  auto sgpr4 = [](const i32x4& r) -> i32x4 {
+    i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane(r.x); rs.y = __builtin_amdgcn_readfirstlane(r.y);
+    rs.z = __builtin_amdgcn_readfirstlane(r.z); rs.w = __builtin_amdgcn_readfirstlane(r.w);
+    return rs;
+  };
   auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
+    // (readfirstlane: a no-op for values the compiler already keeps in scalar registers; it moves descriptors it
+    // decided to park in vector registers back where the instruction needs them)
+    const i32x4& rs = r;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+                 :: "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_base))
                  : "memory", "m0");
   };
+
   // ---- weight DMAs: wave w fetches tap-step ts = w / 4 of a barrier step, rows ((w % 4) NWD + j) * 16 .. + 16 ----
   // lane offset of DMA 0 ; DMA j adds 16 rows through the scalar offset; every
   // row of the tile exists (N % BN == 0, checked by the launcher: the scalar offset is not range checked)
@@ -157,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     r.z = cc < C ? r.z : 0;  // past the last sub-chunk: zero fill (keeps the DMA counts uniform)
     const unsigned soff = cc < C ? (unsigned)(tap * C + cc) * 2u : 0u;
     const unsigned base = smem_base + (unsigned)OFF_W + slot * (unsigned)WSLOT + ts * (unsigned)WTS + (wave_u & 3u) * (unsigned)(NWD * 1024);
+    if (HCONV_ABLATE & 4) return;
 #pragma unroll
     for (int j = 0; j < NWD; ++j) dma(r, wv0, soff + (unsigned)j * wrow16, base + (unsigned)(j * 1024));
   };
@@ -168,9 +197,11 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     const int ccl = first ? cc : cc - g.C1;
     i32x4 r = first ? rX1 : rX2;
     r.z = cc < C ? r.z : 0;
-    const unsigned voff = (pk[p] & 0x1fffffu) * (unsigned)(Cx * 4) + ((tid16 & 48u) << 1);  // + 32 q
+    const unsigned pkp = pk[p];
+    const unsigned voff = (pkp & 0x1fffffu) * (unsigned)(Cx * 4) + ((tid16 & 48u) << 1);  // + 32 q
     const unsigned soff = cc < C ? (unsigned)(ccl * 4) : 0u;
     const unsigned base = smem_base + stg + wave_u * 1024u;
+    if (HCONV_ABLATE & 8) return;
     dma(r, voff, soff, base);
     dma(r, voff, soff + 16u, base + 8192u);  // (an instruction offset would also shift the LDS address)
   };
@@ -179,20 +210,21 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
   // staging -> (affine, SiLU, half) -> patch image `pbuf`; optional raw side output
   auto consume = [&](int p, int cc, unsigned stg, unsigned pbuf) {
     // zero padding is padding of the NORMALISED tensor: pixels outside the image (and channels past the end) become 0
-    const bool ok = (pk[p] & 0x1fffffu) != src_px_u && cc < C;
+    const unsigned pkp = pk[p];
+    const bool ok = (pkp & 0x1fffffu) != src_px_u && cc < C;
     uint32_t w[4], rw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {  // channels 4 hh .. 4 hh + 3 of the thread's 8
       const f32x4 xv = *reinterpret_cast<const f32x4*>(lds + stg + hh * 8192 + tid16);
       f32x4 yv = xv;
-      if (norm) {
+      if (norm && !(HCONV_ABLATE & 1)) {
         const unsigned qo = (tid16 & 48u) >> 1;  // 8 q floats
         const f32x4 av = *reinterpret_cast<const f32x4*>(abt + cc + qo + hh * 4);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(abt + C + cc + qo + hh * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) yv[k] = fmaf(xv[k], av[k], bv[k]);
       }
-      if (do_silu) {
+      if (do_silu && !(HCONV_ABLATE & 1)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           yv[k] = yv[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * yv[k]));
@@ -205,9 +237,9 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
       }
     }
     if (p < 2 || tid16 < (1296u - 1024u) * 16u)  // the item exists (pass 2 has 272 of them)
-      *reinterpret_cast<uint4*>(lds + pbuf + (pk[p] >> 21) * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(lds + pbuf + (pkp >> 21) * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
     if (SIDE && side) {
-      const unsigned voff = ((imask >> p) & 1u) ? (pk[p] & 0x1fffffu) * (unsigned)(C * 2) + (tid16 & 48u) : OOBA;  // + 16 q
+      const unsigned voff = ((imask >> p) & 1u) ? (pkp & 0x1fffffu) * (unsigned)(C * 2) + (tid16 & 48u) : OOBA;  // + 16 q
       i32x4 r = rRaw;
       r.z = cc < C ? r.z : 0;
       const u32x4 d = {rw[0], rw[1], rw[2], rw[3]};
@@ -244,29 +276,55 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     uint4 fb[NR];
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(pw + ni * 1024);
+    if (HCONV_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const uint4 fa = *reinterpret_cast<const uint4*>(pa + mi * 1536);
+      if (HCONV_ABLATE & 2) {
+        asm volatile("" :: "v"(fa));
+        continue;
+      }
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
         // swapped: D[row = n-in-tile = 4*lg + r][col = pixel-in-row = li]
         acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa, acc[ni][mi]);
     }
+    if (HCONV_ABLATE & 2) asm volatile("" :: "v"(fb[0]), "v"(fb[NR - 1]));
+    if (HCONV_SETPRIO) __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: affine table, patch image a of chunk 0 (three passes staged in the still empty weight ring) ----
-  if (norm) {
-    const uint4* src = reinterpret_cast<const uint4*>(g.ab + (int64_t)img * 2 * C);
-    for (int i = tid; i < (2 * C) / 4; i += 512) smem[OFF_AB / 16 + i] = src[i];
+  // ---- prologue: affine table, patch image a of chunk 0 (three passes staged in still empty LDS areas) ----
+  if (HCONV_PRO) {
+    // the three passes of patch image a are staged where nothing lives yet: the patch staging area, ring slot 1 and image b;
+    // ring slot 0 receives the first weight tile meanwhile.  The first step's barrier orders every later writer of those
+    // areas (step 0 refills slot 1 and writes image b only after it).
+    issue_w(0, 0, 0u);
+    issue_patch(0, 0, (unsigned)OFF_STG);
+    issue_patch(1, 0, (unsigned)(OFF_W + WSLOT));
+    issue_patch(2, 0, (unsigned)OFF_PB);
+    if (norm) {
+      const uint4* src = reinterpret_cast<const uint4*>(g.ab + (int64_t)img * 2 * C);
+      for (int i = tid; i < (2 * C) / 4; i += 512) smem[OFF_AB / 16 + i] = src[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    consume(0, 0, (unsigned)OFF_STG, (unsigned)OFF_PA);
+    consume(1, 0, (unsigned)(OFF_W + WSLOT), (unsigned)OFF_PA);
+    consume(2, 0, (unsigned)OFF_PB, (unsigned)OFF_PA);
+    issue_patch(0, 32, (unsigned)OFF_STG);
+  } else {
+    if (norm) {
+      const uint4* src = reinterpret_cast<const uint4*>(g.ab + (int64_t)img * 2 * C);
+      for (int i = tid; i < (2 * C) / 4; i += 512) smem[OFF_AB / 16 + i] = src[i];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) issue_patch(p, 0, (unsigned)(OFF_W + p * STG));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < 3; ++p) consume(p, 0, (unsigned)(OFF_W + p * STG), (unsigned)OFF_PA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // staging areas free: the ring may be filled
+    issue_w(0, 0, 0u);
+    issue_patch(0, 32, (unsigned)OFF_STG);
   }
-#pragma unroll
-  for (int p = 0; p < 3; ++p) issue_patch(p, 0, (unsigned)(OFF_W + p * STG));
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-  for (int p = 0; p < 3; ++p) consume(p, 0, (unsigned)(OFF_W + p * STG), (unsigned)OFF_PA);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // staging areas free: the ring may be filled
-  issue_w(0, 0, 0u);
-  issue_patch(0, 32, (unsigned)OFF_STG);
 
   // ---- main loop.  Step J of chunk c multiplies tap-steps 2J, 2J+1; around it:
   //   weights of the next step -> the other ring slot (waves 0-3 right after the barrier, waves 4-7 between the halves);
@@ -289,22 +347,32 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     const unsigned par = (unsigned)st & 1u;  // (c + J) & 1 == (9 c + J) & 1
     const unsigned wbase = wfrag + par * (unsigned)WSLOT;
     const int jn = J == 8 ? 0 : J + 1, cn = J == 8 ? c + 1 : c;
+    // (a macro, not a nested lambda: with one more closure level SROA gives up and the kernel-argument block lands in scratch)
+#define HCONV_PATCH_WORK()                                                                                     \
+    do {                                                                                                         \
+      if (J <= 2) {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HCONV_ABLATE & 4) ? 0 : NWD) : "memory");                     \
+        consume(J, c * 64 + 32, (unsigned)OFF_STG, (unsigned)OFF_PB);                                            \
+      } else if (J >= 5 && J <= 7) {                                                                             \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HCONV_ABLATE & 4) ? 0 : NWD) : "memory");                     \
+        consume(J - 5, (c + 1) * 64, (unsigned)OFF_STG, (unsigned)OFF_PA);                                       \
+      }                                                                                                          \
+      if (J <= 1) issue_patch(J + 1, c * 64 + 32, (unsigned)OFF_STG);                                            \
+      else if (J >= 4 && J <= 6) issue_patch(J - 4, (c + 1) * 64, (unsigned)OFF_STG);                            \
+      else if (J == 8) issue_patch(0, (c + 1) * 64 + 32, (unsigned)OFF_STG);                                     \
+    } while (0)
     if (!ts) issue_w(jn, cn, par ^ 1u);
     compute(2 * J, wbase);
     if (ts) issue_w(jn, cn, par ^ 1u);
-    __builtin_amdgcn_sched_barrier(0);
-    if (J <= 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWD) : "memory");
-      consume(J, c * 64 + 32, (unsigned)OFF_STG, (unsigned)OFF_PB);
-    } else if (J >= 5 && J <= 7) {
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWD) : "memory");
-      consume(J - 5, (c + 1) * 64, (unsigned)OFF_STG, (unsigned)OFF_PA);
-    }
-    if (J <= 1) issue_patch(J + 1, c * 64 + 32, (unsigned)OFF_STG);
-    else if (J >= 4 && J <= 6) issue_patch(J - 4, (c + 1) * 64, (unsigned)OFF_STG);
-    else if (J == 8) issue_patch(0, (c + 1) * 64 + 32, (unsigned)OFF_STG);
-    __builtin_amdgcn_sched_barrier(0);
+    if (HCONV_FENCE) __builtin_amdgcn_sched_barrier(0);
+    if (!HCONV_LATE_CONSUME || !ts) HCONV_PATCH_WORK();
+    if (HCONV_FENCE) __builtin_amdgcn_sched_barrier(0);
     compute(2 * J + 1, wbase);
+    if (HCONV_LATE_CONSUME && ts) {
+      if (HCONV_FENCE) __builtin_amdgcn_sched_barrier(0);
+      HCONV_PATCH_WORK();
+    }
+#undef HCONV_PATCH_WORK
     if (++J == 9) { J = 0; ++c; }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not outlive the block's LDS

@@ -315,6 +315,9 @@ class Pose2VideoPipeline:
         self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
+        self.shard_force = False    # True: take the sharded code path (unit plan, per-slot async all_gather on the backend's
+        #                             stream, item streams, sharded per-frame stages) even in a group of ONE rank — how the RCCL
+        #                             branch is exercised on a single-GPU box (tests/test_models_gpu.py, bench.py --force-shard)
         self.batch_invariant = False  # True: bit-identical to the sharded run of the same clip (split-K off)
         self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
         self.window_streams = 2     # > 1: the independent windows of one step run on this many HIP streams (single-GPU path)
@@ -393,7 +396,7 @@ class Pose2VideoPipeline:
         world = 1
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.dist_group)
-        with ops.split_k(not (world > 1 or self.batch_invariant)):
+        with ops.split_k(not (world > 1 or self.batch_invariant or (self.shard_windows and self.shard_force))):
             return self._run_tensors(*args, **kwargs)
 
     def _run_tensors(self, ref_image, bk_images, pose_images, clip_embeds, latents, num_inference_steps,
@@ -407,6 +410,8 @@ class Pose2VideoPipeline:
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             import torch.distributed as dist
             rank, world = dist.get_rank(self.dist_group), dist.get_world_size(self.dist_group)
+        sharded = world > 1 or (self.shard_windows and self.shard_force and torch.distributed.is_available()
+                                and torch.distributed.is_initialized())
         sched.set_timesteps(num_inference_steps)
         latents = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
         _, C, F, h, w = latents.shape
@@ -434,6 +439,8 @@ class Pose2VideoPipeline:
             from .image import ImageTokens
             if isinstance(frames, ImageTokens):
                 tok = frames.as_subclass(torch.Tensor)  # already half tokens (image.vae_preprocess)
+                if tok.dtype != self.pose_guider.compute_dtype:
+                    raise TypeError(f"pose image tokens are {tok.dtype}, the pose guider computes in {self.pose_guider.compute_dtype}")
             else:
                 tok = ops.ncfhw_to_tokens(frames.float().contiguous()[:, :, None], self.pose_guider.compute_dtype, cpad=8)
             return torch.cat([self.pose_guider.run_tokens(tok[i:i + self.vae_batch].contiguous())
@@ -449,7 +456,7 @@ class Pose2VideoPipeline:
         reader = ReferenceAttentionControl(unet, mode="read", do_classifier_free_guidance=cfg)
         main = torch.cuda.current_stream(dev)
         side = None
-        if world == 1 and self.window_streams > 1:
+        if not sharded and self.window_streams > 1:
             side = self._streams(dev)[0]
             side.wait_stream(main)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), ops.workspace_slot(1 if side is not None else 0):
@@ -462,7 +469,7 @@ class Pose2VideoPipeline:
             except EarlyExit:
                 pass
 
-        if world > 1:  # one long clip over the ranks: the per-frame stages are sharded too
+        if sharded:  # one long clip over the ranks: the per-frame stages are sharded too
             bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev), rank, world, self.dist_group).to(dt)
             pose_tok = sharded_frames(pose_fn, pose_images.to(dev), rank, world, self.dist_group)
         else:
@@ -481,7 +488,7 @@ class Pose2VideoPipeline:
                                                           context_overlap)
         win_idx = [torch.tensor(c, dtype=torch.int32, device=dev) for c in windows]
         win_pose = [pose_tok[c.long()] for c in win_idx]
-        rep = (2 if cfg else 1) if world == 1 else 1
+        rep = (2 if cfg else 1) if not sharded else 1
         # Per-window UNet input [rep * Fw, h, w, 8] = (latent | background) channels, allocated once per clip: the
         # background half is constant and written here for every CFG copy, the latent half is rewritten every step by
         # the layout kernel (one launch per CFG copy) — no torch.cat / repeat inside the step loop.
@@ -503,7 +510,7 @@ class Pose2VideoPipeline:
         # instead of four M = 2 launches per forward (they depend on (t, clip embedding) only)
         temb_tab, attn2_tab = unet.clip_tables(steps_t, ehs, 2 if cfg else 1)
         units, my_units = plan_units(len(windows), cfg, rank, world)
-        my_items = plan_items(len(windows), cfg, world)[rank] if world > 1 else []
+        my_items = plan_items(len(windows), cfg, world)[rank] if sharded else []
         item_x, item_pose = [], []
         for item in my_items:  # per-item UNet input / pose buffers of the sharded mode (same layout as win_x)
             c = win_idx[item[0][0]]
@@ -511,9 +518,9 @@ class Pose2VideoPipeline:
             xw[..., C:] = bk_tok[c.long()].repeat(len(item), 1, 1, 1)
             item_x.append(xw)
             item_pose.append(pose_tok[c.long()].repeat(len(item), 1, 1, 1))
-        counter_x = torch.empty((F,), device=dev, dtype=torch.float32)  # the cond half's (unused) frame counter
+        counter_x = torch.zeros((F,), device=dev, dtype=torch.float32)  # the cond half's (unused) frame counter
         exch = None
-        if world > 1:  # every window has the same frame count; the UNet's output head is padded to 4 channels
+        if sharded:  # every window has the same frame count; the UNet's output head is padded to 4 channels
             cpad = (unet.out_channels + 3) // 4 * 4
             exch = UnitExchange(units, rank, world, (len(windows[0]), h, w, cpad), dev, self.dist_group)
         gather_marks = []
@@ -525,7 +532,7 @@ class Pose2VideoPipeline:
             acc.zero_()
             counter.zero_()
             preds = {}
-            if world == 1 and len(win_idx) > 1 and self.window_streams > 1 and not self.use_graphs:
+            if not sharded and len(win_idx) > 1 and self.window_streams > 1 and not self.use_graphs:
                 # The windows of one step are independent forwards: on two streams their kernels fill each other's idle
                 # CUs (tail rounds of small levels, HBM-bound linears beside MFMA-bound convolutions): -4.7 % per step at
                 # two windows (profiles/r2_two_stream_forward.txt).  Accumulation stays in canonical window order.
@@ -543,7 +550,7 @@ class Pose2VideoPipeline:
                 for pred, idx in zip(wpred, win_idx):
                     pred.record_stream(main)
                     ops.window_accumulate(pred, idx, acc, counter)
-            elif world == 1:
+            elif not sharded:
                 for wi, idx in enumerate(win_idx):
                     x = fill_latents(wi)                                                         # [rep*Fw,h,w,8]
                     if self.use_graphs:
@@ -618,7 +625,7 @@ class Pose2VideoPipeline:
         mark("denoising_loop")
         if not decode:
             return latents
-        if world > 1:
+        if sharded:
             fr = sharded_frames(lambda z: self._decode_frames(z.permute(1, 0, 2, 3)[None].contiguous())[0].permute(1, 0, 2, 3),
                                 latents[0].permute(1, 0, 2, 3).contiguous(), rank, world, self.dist_group)
             video = fr.permute(1, 0, 2, 3)[None].contiguous()

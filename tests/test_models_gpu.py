@@ -341,7 +341,28 @@ def _sharded_clip_worker(rank, world, port, q, F=26):
         dist.destroy_process_group()
 
 
-def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0):
+def _rccl_world1_worker(port, q, F):
+    """One rank, backend "nccl" (= RCCL): the sharded code path forced on (pipe.shard_force), so that every collective of
+    the long-clip mode — the per-slot async all_gather_into_tensor of UnitExchange on RCCL's stream, the all_gather of the
+    sharded per-frame stages — actually runs on RCCL."""
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        out = _small_clip(dev, shard=True, F=F, force=True)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)  # the reduction bench.py takes its max-over-ranks time with
+        torch.cuda.synchronize()
+        q.put(("ok", out.cpu().numpy(), float(t.sum())))
+    except Exception as e:  # surface the failure in the parent instead of a queue timeout
+        q.put(("error", repr(e), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0, force=False):
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -358,6 +379,7 @@ def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, de
     lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
     pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
     pipe.shard_windows, pipe.batch_invariant = shard, invariant
+    pipe.shard_force = force
     if window_streams is not None:
         pipe.window_streams = window_streams
     if delay_main_cycles:  # the main stream falls far behind the host: whatever a side stream needs from it must be ordered by events
@@ -414,6 +436,27 @@ def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F):
     assert torch.isfinite(single).all()
     assert all(torch.equal(res[r], single) for r in range(world))
     report(f"sharded long clip ({world} ranks, F = {F}, plan item sizes {kinds}, 2 steps, fp16): latents and video bit-identical to the single-process run")
+
+
+@pytest.mark.parametrize("F", [26, 50])
+def test_rccl_branch_world1_equals_plain_run_bit_for_bit(dev, F):
+    """The `nccl` (RCCL) branch of the long-clip mode on the one GPU of this box: a process group of ONE rank with the
+    sharded path forced on runs the unit plan (whole windows as b = 2 items on alternating HIP streams), UnitExchange's
+    async all_gather_into_tensor per slot on RCCL's stream, and the sharded per-frame stages' all_gather — and reproduces the
+    plain single-process run bit for bit (F = 26: two windows, two exchange slots x 2 units; F = 50: three windows)."""
+    import torch.multiprocessing as mp
+    single = _small_clip(dev, invariant=True, F=F).cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400 + 431 + F
+    p_ = ctx.Process(target=_rccl_world1_worker, args=(port, q, F))
+    p_.start()
+    status, val, ar = q.get(timeout=900)
+    p_.join(timeout=120)
+    assert status == "ok", val
+    assert ar == 4.0
+    assert torch.equal(torch.from_numpy(val), single)
+    report(f"RCCL branch (backend nccl, world 1, forced sharding, F = {F}): latents and video bit-identical to the plain run")
 
 
 def test_pipeline_call_surface_pil_inputs(dev):
