@@ -661,7 +661,10 @@ class Pose2VideoPipeline:
     def __call__(self, ref_image, pose_images, vid_bk_images, width, height, video_length, num_inference_steps,
                  guidance_scale, num_images_per_prompt=1, eta=0.0, generator=None, output_type="tensor",
                  return_dict=True, callback=None, callback_steps=1, context_schedule="uniform", context_frames=24,
-                 context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
+                 context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1, output_device=False,
+                 **kwargs):
+        """output_device=True (not in the reference): `.videos` stays an fp32 DEVICE tensor — what mimo_amd.run_edit hands to
+        the device-side compositing instead of the reference's per-frame `.cpu().numpy()` round trips."""
         if eta != 0.0:
             raise NotImplementedError("eta = 0 (DDIM, the reference's setting) only")
         if context_batch_size != 1:
@@ -700,6 +703,8 @@ class Pose2VideoPipeline:
         else:
             video = self.run_tensors(ref_t, bk_t, pose_t, clip_embeds, latents.float(), num_inference_steps, guidance_scale,
                                      context_schedule, context_frames, context_stride, context_overlap, callback=cb)
+        if output_device:
+            return Pose2VideoPipelineOutput(videos=video.float()) if return_dict else video.float()
         images = video.cpu().float()
         if output_type != "tensor":
             images = images.numpy()

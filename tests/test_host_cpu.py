@@ -599,6 +599,59 @@ def test_template_functions_match_reference_tools_util():
     assert np.array_equal(T.crop_img(img, m), ns["crop_img"](img, m))
 
 
+def test_run_edit_frame_selection_known_answers():
+    """run_edit.keep_frame_indices / time_crop_range: the codec-free arithmetic of load_video_fixed_fps
+    (tools/util.py:462-479) and of the time crop (run_edit.py:194-198)."""
+    from mimo_amd.run_edit import keep_frame_indices, time_crop_range
+    assert keep_frame_indices(10, 30, 30) == list(range(10))
+    assert keep_frame_indices(10, 29.97, 15) == [0, 2, 4, 6, 8]            # fps metadata is rounded first
+    assert keep_frame_indices(7, 25, 30) == [0, 0, 1, 2, 3, 4, 5, 5, 6][:9]  # up-sampling repeats frames (floor of k * 25/30)
+    assert keep_frame_indices(5, 60, 24) == [0, 2]
+    assert keep_frame_indices(0, 30, 30) == []
+    assert time_crop_range(30, 10, 100, 40) == (10, 40)
+    assert time_crop_range(15, 10, 100, 60) == (5, 50)
+    assert time_crop_range(24, -3, 7, 60) == (0, 5)
+
+
+@pytest.mark.reference
+def test_run_edit_frame_selection_matches_reference_loader():
+    """keep_frame_indices == the frames tools/util.py `load_video_fixed_fps` returns, the reference function executed from
+    its source with a stand-in `imageio` reader whose frame i is the constant image i."""
+    import ast
+    import types
+    import numpy as np
+    from PIL import Image
+    from mimo_amd.run_edit import keep_frame_indices
+    tree = ast.parse(open("/root/reference/tools/util.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "load_video_fixed_fps"]
+    assert keep
+
+    class Reader:
+        def __init__(self, n, fps):
+            self.n, self.fps = n, fps
+
+        def get_meta_data(self):
+            return {"fps": self.fps}
+
+        def count_frames(self):
+            return self.n
+
+        def __len__(self):
+            return self.n
+
+        def get_data(self, i):
+            return np.full((2, 2, 3), i, np.uint8)
+
+        def close(self):
+            pass
+
+    for n, fps, tfps in ((10, 30, 30), (37, 29.97, 15), (7, 25, 30), (100, 60, 24), (13, 23.976, 30), (1, 30, 30)):
+        ns = {"np": np, "Image": Image, "imageio": types.SimpleNamespace(get_reader=lambda path, n=n, fps=fps: Reader(n, fps))}
+        exec(compile(ast.Module(body=keep, type_ignores=[]), "tools/util.py", "exec"), ns)
+        frames = ns["load_video_fixed_fps"]("x.mp4", target_fps=tfps)
+        assert [int(np.asarray(f)[0, 0, 0]) for f in frames] == keep_frame_indices(n, fps, tfps), (n, fps, tfps)
+
+
 @pytest.mark.reference
 def test_interpolate_latents_matches_reference():
     """mimo_amd.pipeline.interpolate_latents == Pose2VideoPipeline.interpolate_latents (:293-336) with both methods of

@@ -459,6 +459,104 @@ def test_rccl_branch_world1_equals_plain_run_bit_for_bit(dev, F):
     report(f"RCCL branch (backend nccl, world 1, forced sharding, F = {F}): latents and video bit-identical to the plain run")
 
 
+def _edit_template(n=44, H=120, W=160, seed=0):
+    """A synthetic video-editing template: pose frames with a textured person blob that walks right and grows (the ROI-clip
+    cutter fires), random video / background frames, an occluder mask that sweeps through."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    pose, vid, bk, occ = [], [], [], []
+    for i in range(n):
+        f = np.zeros((H, W, 3), np.uint8)
+        cx, cy = 30 + 2 * i, H // 2
+        hw = 10 + (0 if i < 20 else 2 * (i - 20))
+        hh = 25 + (0 if i < 25 else (i - 25))
+        y0, y1, x0, x1 = max(0, cy - hh), min(H, cy + hh), max(0, cx - hw), min(W, cx + hw)
+        f[y0:y1, x0:x1] = rs.randint(30, 255, (y1 - y0, x1 - x0, 3))
+        pose.append(f)
+        vid.append(rs.randint(0, 255, (H, W, 3), dtype=np.uint8))
+        bk.append(rs.randint(0, 255, (H, W, 3), dtype=np.uint8))
+        o = np.zeros((H, W, 3), np.uint8)
+        o[:, max(0, 3 * i - 10):3 * i + 12] = 255
+        o[H // 3:H // 2, :] //= 2  # soft occluder values too
+        occ.append(o)
+    return pose, vid, bk, occ
+
+
+def test_run_edit_end_to_end_vs_oracle_chain(dev):
+    """BASELINE configs[2] as ONE path: mimo_amd.run_edit.MIMO.run (run_edit.py:153-306: reference crop + pad, frame-rate
+    selection + time crop, ROI-clip segmentation, per-frame padding, Pose2VideoPipeline.__call__, per-frame compositing with
+    edge mask / occluder / clip cross-fade) on a synthetic template with two clips and an occluder, against the oracle
+    chain — the SAME host-side template functions (bit-exact vs the reference's own tools/util.py in test_host_cpu.py),
+    the CPU fp32 oracle pipeline, and oracle/edit.py (the numpy / PIL restatement of run_edit.py:253-304).
+    uint8 frames: the compositing itself is bit-exact (checked here on the oracle's video); end to end the only difference
+    is the fp16 pipeline, i.e. +-1 grey level where `(image * 255).astype(np.uint8)` truncates next to an integer."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd import edit as E
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    from mimo_amd.edit import MASK_MODE
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.run_edit import MIMO, Template
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import edit as OE
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    dtype = torch.float16
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=81)
+    ov, pv = build_pair_vae(dtype, dev, seed=82)
+    og, pg = build_pair_pose(dtype, dev, seed=83)
+    ccfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                            image_size=224, patch_size=32, projection_dim=768)
+    torch.manual_seed(5)
+    oclip = RefCLIP(ccfg).eval()
+    pclip = CLIPVisionModelWithProjection(ccfg)
+    pclip.load_state_dict({k: v for k, v in oclip.state_dict().items() if not k.endswith("position_ids")})
+    pclip.to(dev)
+    pclip.compute_dtype = dtype
+    pipe = Pose2VideoPipeline(vae=pv, image_encoder=pclip, reference_unet=p2, denoising_unet=p3, pose_guider=pg,
+                              scheduler=DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    rs = np.random.RandomState(3)
+    mask_list = [rs.rand(64, 64).astype(np.float32) for _ in MASK_MODE]
+    pose, vid, bk, occ = _edit_template()
+    tpl = Template(vid, pose, bk, occ, fps=30, target_fps=15, time_crop={"start_idx": 2, "end_idx": 80})
+    ref_img = rs.randint(0, 256, (90, 70, 3), dtype=np.uint8)
+    ref_mask = np.zeros((90, 70), np.uint8)
+    ref_mask[10:80, 12:60] = 255
+    H = W = 64
+    m = MIMO(pipe, mask_list, width=W, height=H, steps=2, cfg=3.5, seed=42)
+    res, fps = m.run(ref_img, tpl, ref_mask=ref_mask)
+    la = m.last
+    assert fps == 15 and len(res) == m.L == 21 and len(la["context_list"]) == 2
+    F = sum(len(c) for c in la["context_list"])
+    assert F == len(la["pose_list"]) > m.L  # the clips overlap by `overlay` frames
+    assert all(r.dtype == np.uint8 and r.shape == (120, 160, 3) for r in res)
+    # ---- oracle chain on the same prepared inputs ----
+    to_t = lambda im: torch.from_numpy(np.array(im.resize((W, H), Image.LANCZOS)).astype(np.float32) / 255.0).permute(2, 0, 1)
+    px = CLIPImageProcessor().preprocess(la["ref_image"].resize((224, 224)), return_tensors="pt").pixel_values
+    with torch.no_grad():
+        emb = oclip(pixel_values=px).image_embeds
+        lat = torch.randn((1, 4, F, H // 8, W // 8), generator=torch.manual_seed(42))
+        vid_o, _ = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), emb,
+                            (2 * to_t(la["ref_image"]) - 1)[None], torch.stack([2 * to_t(b) - 1 for b in la["bk_list"]]),
+                            torch.stack([to_t(p) for p in la["pose_list"]]), lat, 2, 3.5)
+    vid_f, bk_f, occ_f = la["frames"]
+    args = (la["context_list"], la["bbox_clip_list"], la["clip_pad_list"], la["clip_padv_list"], bk_f, vid_f, occ_f, la["masks"])
+    res_o = OE.composite(vid_o[0].float(), *args, 4, m.L)
+    # the compositing stage alone, on the oracle's video: bit-exact
+    dev_o = E.composite_clips(vid_o[0].float().contiguous().to(dev), *args, overlay=4, L=m.L).cpu().numpy()
+    assert all(np.array_equal(dev_o[i], res_o[i]) for i in range(m.L))
+    # end to end
+    d = np.abs(np.stack(res).astype(np.int32) - np.stack(res_o).astype(np.int32))
+    e_vid = rel_l2(la["video"].cpu(), vid_o[0])
+    report(f"run_edit MIMO.run end to end ({len(la['context_list'])} clips, {F} generated / {m.L} output frames, occluder, fp16): "
+           f"video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, max |d|={int(d.max())}, "
+           f"{100 * float((d > 1).mean()):.3f} % of values off by more than 1")
+    assert e_vid < 2e-3
+    assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
+
+
 def test_pipeline_call_surface_pil_inputs(dev):
     """The reference's call surface (run_animate.py:208-218 / run_edit.py): PIL reference image, lists of PIL pose and
     per-frame background images (config 3: non-constant backgrounds), CPU generator, `.videos` [1,3,F,H,W] float32 on the
