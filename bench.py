@@ -233,9 +233,8 @@ def cpu_baseline(clip_flops, frames, budget_s=25.0, config2=False):
                         f"(BASELINE configs[{1 if config2 else 0}] size), {n} timed: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => "
                         f"{cpu_flops_per_s/1e12:.3f} TFLOP/s; extrapolated to the clip's {clip_flops/1e12:.1f} executed TFLOP "
                         f"(model build {build_s:.0f} s untimed)"
-                        + ("" if config2 else "; configs[0] -> configs[1] shape ratio of the CPU rate, measured on the reference's own "
-                           "code in the build container (8 cores): 0.50 -> 0.483 TFLOP/s = 0.96 (SURVEY 8c); on a 32-thread MI355X host: "
-                           "profiles/r3_cpu_baseline_config2.json")))
+                        + ("" if config2 else "; QUICK sample: at the workload's own configs[1] shape a 32-thread MI355X host sustains "
+                           "0.61x this rate (profiles/r3_cpu_baseline_config2.json) — run without --cpu-baseline-quick for that number")))
 
 
 def bf16_record(pipe, dev, inp, a, fp16_forward_out):
@@ -253,13 +252,15 @@ def bf16_record(pipe, dev, inp, a, fp16_forward_out):
 
     clip()
     torch.cuda.synchronize()
+    n = 3
     t0 = time.perf_counter()
-    clip()
+    for _ in range(n):
+        clip()
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el = (time.perf_counter() - t0) / n
     out = forward_output(pipe, dev, dt, a.size)
     rel = float((out.float() - fp16_forward_out.float()).norm() / fp16_forward_out.float().norm())
-    return {"value": a.frames / el, "unit": "frames/s", "ms_per_step": el * 1e3, "steps": 1, "forward_rel_l2_vs_fp16": rel}
+    return {"value": a.frames / el, "unit": "frames/s", "ms_per_step": el * 1e3, "steps": n, "forward_rel_l2_vs_fp16": rel}
 
 
 def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16, fam_fp16):
@@ -278,6 +279,47 @@ def fp8_qk_record(pipe, dev, dtype, size, fp16_forward_out, t_fwd_fp16, fam_fp16
     return {"forward_rel_l2_vs_16bit_qk": rel, "forward_ms_fp8_qk": t8 * 1e3, "forward_ms_16bit_qk": t_fwd_fp16 * 1e3,
             "spatial_attention_fp8_qk": att(fam8), "spatial_attention_16bit_qk": att(fam_fp16),
             "note": "opt-in (ops.fp8_qk / mimo_attention_fp8qk): Q.K^T on v_mfma_f32_32x32x16_fp8_fp8, softmax and P.V unchanged"}
+
+
+def edit_record(pipe, dev, a):
+    """BASELINE configs[2] (`--edit`): the run_edit.py path as ONE timed unit — mimo_amd.run_edit.MIMO.run on a synthetic
+    template (24 frames of a.size x a.size video / pose / background / occluder, one person blob that fills most of the
+    frame): frame selection, ROI-clip segmentation and padding on the host, Pose2VideoPipeline.__call__ (PIL inputs, device
+    pre-processing, CLIP, VAE, both UNets), and the per-frame compositing (resize, un-pad, paste, edge mask, occluder) on
+    the device, result frames copied to the host — all inside the timed region."""
+    import numpy as np
+    from mimo_amd.edit import MASK_MODE
+    from mimo_amd.run_edit import MIMO, Template
+    rs = np.random.RandomState(11)
+    S, n = a.size, a.frames
+    pose, vid, bk, occ = [], [], [], []
+    for i in range(n):
+        f = np.zeros((S, S, 3), np.uint8)
+        x0 = S // 8 + i
+        f[S // 16:S - S // 16, x0:x0 + S // 2] = rs.randint(30, 255, (S - S // 8, S // 2, 3))
+        pose.append(f)
+        vid.append(rs.randint(0, 255, (S, S, 3), dtype=np.uint8))
+        bk.append(rs.randint(0, 255, (S, S, 3), dtype=np.uint8))
+        o = np.zeros((S, S, 3), np.uint8)
+        o[:, 4 * i:4 * i + S // 10] = 255
+        occ.append(o)
+    tpl = Template(vid, pose, bk, occ, fps=30)
+    mask_list = [rs.rand(256, 256).astype(np.float32) for _ in MASK_MODE]
+    ref = rs.randint(0, 256, (S, S * 3 // 4, 3), dtype=np.uint8)
+    m = MIMO(pipe, mask_list, width=S, height=S, steps=a.ddim_steps, cfg=a.guidance, seed=42)
+    m.run(ref, tpl)  # warm-up
+    torch.cuda.synchronize()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res, _ = m.run(ref, tpl)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    gen = sum(len(c) for c in m.last["context_list"])
+    return {"value": len(res) / el, "unit": "output frames/s", "ms_per_clip": el * 1e3, "clips": reps, "output_frames": len(res),
+            "generated_frames": gen, "roi_clips": len(m.last["context_list"]),
+            "workload": f"BASELINE configs[2]: MIMO.run (run_edit.py:153-306) on a synthetic {S}x{S} template of {n} frames with occluder: "
+                        "host template preparation + Pose2VideoPipeline.__call__ + device compositing + frames to the host"}
 
 
 def forward_output(pipe, dev, dtype, size):
@@ -333,6 +375,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--guidance", type=float, default=3.5)
+    ap.add_argument("--edit", action="store_true", help="add the `edit` sub-record: BASELINE configs[2], the whole run_edit.py path timed")
     ap.add_argument("--shard-windows", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="with --shard-windows under torchrun at world size 1: take the sharded (RCCL) code path anyway")
@@ -345,12 +388,14 @@ def main():
     ap.add_argument("--fp8-qk", action="store_true", help="add the fp8 Q.K^T sub-record (BASELINE configs[4]): accuracy and time "
                     "of one denoising forward with the spatial attentions' Q.K^T on the e4m3 MFMA")
     ap.add_argument("--tile-vae", type=int, default=0, help="VAE tiled decode (exact row bands of this many rows; BASELINE configs[4])")
-    ap.add_argument("--cpu-baseline-config2", action="store_true", help="time the CPU baseline at configs[1] shapes (one forward "
-                    "on 2 x 24 frames at latent 64 x 64: about a minute on 32 threads) instead of configs[0] shapes")
+    ap.add_argument("--cpu-baseline-config2", action="store_true", help=argparse.SUPPRESS)  # (the default since round 4)
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="time the CPU baseline on a configs[0]-shaped forward (2 x 8 "
+                    "frames at latent 32 x 32, a few seconds) instead of ONE forward at the workload's own configs[1] shape (about a "
+                    "minute on 32 threads): quicker, but the CPU sustains ~1.5x the rate there, which flatters it")
     ap.add_argument("--cpu-baseline-only", type=float, default=0.0, help=argparse.SUPPRESS)  # child mode: clip FLOPs
     a = ap.parse_args()
     if a.cpu_baseline_only > 0:
-        print(json.dumps(cpu_baseline(a.cpu_baseline_only, a.frames, config2=a.cpu_baseline_config2)), flush=True)
+        print(json.dumps(cpu_baseline(a.cpu_baseline_only, a.frames, config2=not a.cpu_baseline_quick)), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -460,6 +505,11 @@ def main():
                 out["bf16"] = bf16_record(pipe, dev, inp, a, forward_output(pipe, dev, dtype, a.size))
             except Exception as e:  # informational sub-record: never lose the headline line
                 out["bf16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if a.edit and world == 1:
+            try:
+                out["edit"] = edit_record(pipe, dev, a)
+            except Exception as e:
+                out["edit"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if a.fp8_qk and world == 1:
             try:
                 out["fp8_qk"] = fp8_qk_record(pipe, dev, dtype, a.size, forward_output(pipe, dev, dtype, a.size), t_fwd, fam)
@@ -470,13 +520,13 @@ def main():
             try:  # child process with a hard wall-clock bound: the baseline is informational, never lose the GPU line
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
                                     str(float(clip_flops or fwd_flops * a.ddim_steps)), "--frames", str(a.frames)]
-                                   + (["--cpu-baseline-config2"] if a.cpu_baseline_config2 else []),
-                                   capture_output=True, text=True, timeout=600 if a.cpu_baseline_config2 else 240,
+                                   + (["--cpu-baseline-quick"] if a.cpu_baseline_quick else []),
+                                   capture_output=True, text=True, timeout=240 if a.cpu_baseline_quick else 600,
                                    env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
                 out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": min(os.cpu_count(), 32), "kind": "port",
-                                       "sample": f"not measured within 240 s: {type(e).__name__}"}
+                                       "sample": f"not measured within {240 if a.cpu_baseline_quick else 600} s: {type(e).__name__}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
