@@ -1,7 +1,7 @@
 """The OpenCV primitives the reference's template pre/post-processing calls (tools/util.py, run_edit.py:284), on NumPy.
 
 cv2 is not part of this image (no network), so these follow OpenCV 4.x's documented algorithms:
-  rgb2gray            cv2.cvtColor(img, cv2.COLOR_RGB2GRAY), 8-bit: (R 4899 + G 9617 + B 1868 + 2^13) >> 14
+  rgb2gray            cv2.cvtColor(img, cv2.COLOR_RGB2GRAY), 8-bit (OpenCV 4.x: 15-bit weights): (R 9798 + G 19235 + B 3735 + 2^14) >> 15
   morphology_rect     cv2.morphologyEx(mask, MORPH_CLOSE | MORPH_OPEN, getStructuringElement(MORPH_RECT, (k, k))):
                       anchor = k // 2, the border never contributes (morphologyDefaultBorderValue)
   bounding_rect       cv2.boundingRect(mask) of the non-zero pixels -> (x, y, w, h); (0, 0, 0, 0) when empty
@@ -18,9 +18,12 @@ import numpy as np
 
 
 def rgb2gray(img):
-    """uint8 [H, W, 3] RGB -> uint8 [H, W] (fixed-point BT.601 weights, yuv_shift = 14, rounded)."""
+    """uint8 [H, W, 3] RGB -> uint8 [H, W]: OpenCV 4.x's 8-bit COLOR_RGB2GRAY (color_yuv.simd.hpp: RY15 = 9798, GY15 = 19235,
+    BY15 = 3735, gray_shift = 15, rounded).  OpenCV 3.x used the 14-bit weights 4899 / 9617 / 1868: the two differ by one
+    grey level on ~0.1 % of the colours, which matters only next to the `gray > 10` threshold of extract_mask_sdc.  The
+    reference pins no OpenCV version (it arrives through controlnet-aux): the 4.x arithmetic is the one installed today."""
     a = img.astype(np.int32)
-    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((a[..., 0] * 9798 + a[..., 1] * 19235 + a[..., 2] * 3735 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def _shifted_reduce(m, k, fn, fill):

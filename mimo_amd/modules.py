@@ -307,7 +307,9 @@ class _FeedForward(nn.Module):
 def _ff_fusable(p, n3, out_f32):
     # (batch-invariant runs — split-K off — take the fused kernel whatever the row count: a b = 1 unit and the b = 2 launch
     # of the same window must go through the same kernel, the two forms differ in their fp32 summation order)
-    return ops.FF_FUSED and not out_f32 and p.get("ff2_wk") is not None and \
+    # (FF_FUSED_MAX_ROWS: the fused kernels address their operands with 32-bit byte offsets and return MIMO_EINVAL beyond
+    # it — such a launch takes the 3-4 launch path instead of raising)
+    return ops.FF_FUSED and not out_f32 and p.get("ff2_wk") is not None and n3.shape[0] <= ops.FF_FUSED_MAX_ROWS and \
         (n3.shape[0] >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled())
 
 

@@ -251,6 +251,7 @@ FF_PROJ_FUSED = True      # ... and the block's output projection + residual fol
 BLOCK_TAIL_FUSED = True   # ... and the attention output projection + the LayerNorm in front (mimo_block_tail_fused)
 FF_FUSED_DIM = 320
 FF_FUSED_MIN_ROWS = 8192
+FF_FUSED_MAX_ROWS = (2 ** 31 - 1) // (4 * 320) - 128   # (M - 1) * ld + C must stay below 2^31 bytes for the fp32 operands (ld = 320)
 
 
 def ff_fused(a, w1p, b1p, w2k, b2, residual):

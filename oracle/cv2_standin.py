@@ -2,7 +2,7 @@
 tests execute from /root/reference/tools/util.py via `ast` (cv2 itself is not in this image): written on scipy.ndimage /
 plain NumPy, independently of mimo_amd/cvops.py, from the documented OpenCV semantics of each call.
 
-  cvtColor(img, COLOR_RGB2GRAY)          8-bit fixed point: (4899 R + 9617 G + 1868 B + 8192) >> 14
+  cvtColor(img, COLOR_RGB2GRAY)          8-bit fixed point, OpenCV 4.x: (9798 R + 19235 G + 3735 B + 16384) >> 15
   getStructuringElement(MORPH_RECT, k)   all-ones k x k
   morphologyEx(m, MORPH_CLOSE | MORPH_OPEN, se)   window anchored at k // 2, border never contributes
   boundingRect(m)                        (x, y, w, h) of the non-zero pixels, (0, 0, 0, 0) if none
@@ -18,7 +18,7 @@ def cvtColor(img, code):
     assert code == COLOR_RGB2GRAY and img.dtype == np.uint8
     out = np.empty(img.shape[:2], np.uint8)
     flat = img.reshape(-1, 3).tolist()
-    out.reshape(-1)[:] = [(4899 * r + 9617 * g + 1868 * b + 8192) // 16384 for r, g, b in flat]
+    out.reshape(-1)[:] = [(9798 * r + 19235 * g + 3735 * b + 16384) // 32768 for r, g, b in flat]
     return out
 
 

@@ -304,6 +304,5 @@ def test_hip_multiwindow_call_vs_reference_golden(full_models):
             f" | decoded frames 0/47: {v0:.2e} {v47:.2e}")
     print(line)
     _report(line)
-    # the 1e-3 bar on one forward (step 0) and on the decoded frames; the chained 4-step latents (four 250-step jumps, like
-    # config 1) measured 9.2e-4 and get the same x 1.3 headroom as the other chained fixtures
-    assert e0 < 1e-3 and e3 < 1.2e-3 and max(v0, v47) < 1e-3
+    # the 1e-3 bar everywhere on this fixture (the chained 4-step latents measure 9.1e-4)
+    assert e0 < 1e-3 and e3 < 1e-3 and max(v0, v47) < 1e-3
