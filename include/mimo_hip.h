@@ -174,6 +174,11 @@ int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_
  * stats: fp32 [n, groups, 2] = (mean, rstd), exactly what mimo_group_norm_apply consumes. */
 int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
                                int groups, float eps, float* stats, void* stream);
+/* The same merge for partials over `rows_per_slab` pixels each (HW % rows_per_slab == 0): 32 = the column statistics of
+ * mimo_gemm_ext / mimo_conv2d_ext, 256 = the tile statistics of mimo_conv3x3_fused.  Both sources of a virtual concat must
+ * use the same slab size and slab order (image-major). */
+int mimo_group_norm_stats_slabs(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW, int rows_per_slab,
+                                int groups, float eps, float* stats, void* stream);
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);
@@ -199,6 +204,10 @@ int mimo_group_norm_affine(const float* stats, const float* gamma, const float* 
  *   out: fp32 [n, H, W, Cout]; H % 16 == 0, W % 16 == 0 (a block owns a 16 x 16 pixel tile + halo).
  *   raw_out (nullable, not with upsample2x): half16 [n, H, W, C] plain cast of x, written as a side effect (it feeds
  *       the fused 1x1 shortcut of the block's second convolution through mimo_conv2d's in2).
+ *   tile_stats (nullable): fp32 [n * (H/16) * (W/16)][2][Cout]: per 16 x 16 pixel tile and output channel, the mean and the
+ *       sum of squared deviations from that mean of the values this call stores (exact two-pass inside the tile, fixed
+ *       order).  mimo_group_norm_stats_cols(..., rows_per_slab = 256) merges them into GroupNorm (mean, rstd): the
+ *       norm that consumes `out` makes no statistics pass over HBM.  Not with a residual / MIMO_EPI_SILU (MIMO_EINVAL).
  *   epilogue: bias [Cout], img_bias row = image / imgs_per_bias_row (the time embedding), MIMO_EPI_SILU,
  *       residual fp32 [n, H, W, Cout], out_scale.  flags must contain MIMO_EPI_OUT_F32 (and MIMO_EPI_RES_F32 with a
  *       residual).  Returns MIMO_EINVAL for shapes it does not cover (the caller then takes the two-launch path);
@@ -214,8 +223,8 @@ typedef struct mimo_hconv_params {
 
 int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const float* x2, int C2, const float* ab, int silu,
                        const void* W, int64_t ldw, float* out, const mimo_hconv_params* p, const float* bias,
-                       const float* img_bias, const float* residual, void* raw_out, float out_scale,
-                       unsigned flags, void* stream);
+                       const float* img_bias, const float* residual, void* raw_out, float* tile_stats,
+                       float out_scale, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * LayerNorm over the last dim of x [rows, C] (fp32 or half16) -> half16 `out` and / or fp32 `out_f32`, optional

@@ -65,6 +65,7 @@ struct HArgs {
   const float* img_bias;  // [n / imgs_per_bias_row][ldib] or null
   const float* res;       // fp32 [n, H, W, N] or null
   uint16_t* raw;          // optional side output: half16 cast of the un-normalised input [n, H, W, C]
+  float* tstats;          // optional side output: per (16 x 16 tile, output channel) mean and centred sum of squares [tiles][2][N]
   int64_t ldw, ldib;
   int C1, C2, n, H, Wd, Hs, Ws, ups, N, tiles_n, tiles_x, tiles_y, silu, epi_silu, imgs_per_bias_row;
   float out_scale;
@@ -75,7 +76,7 @@ constexpr unsigned OOBA = 0x80000000u;  // every descriptor is < 2 GiB: OOBA (+ 
 constexpr int PB = 18 * 24 * 64;        // bytes of one patch image: 18 rows x 24-pixel pitch x 32 half channels
 constexpr int STG = 16384;              // staging bytes of one patch pass: 512 threads x 2 x 16 B
 
-template <int DT, int NR, int WM, int WN, int ABMAX, bool NORM, bool SIDE>
+template <int DT, int NR, int WM, int WN, int ABMAX, bool NORM, bool SIDE, bool TSTATS>
 __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
   static_assert(WM * WN == 8, "8 waves");
   constexpr int MT = 16 / WM;       // tile rows (= 16-pixel MFMA column tiles) per wave
@@ -401,6 +402,71 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
       col_ok[ni] = nn < g.N;
       bv[ni] = ld4(r_bias, col_ok[ni] ? (unsigned)nn * 4u : OOB) + ld4(r_imgb, col_ok[ni] ? (unsigned)nn * 4u : OOB);
     }
+    // ---- optional: GroupNorm statistics of the tensor this launch writes, per 256-pixel tile and channel ----
+    // (mean, sum of squared deviations from that mean).  Without a residual the stored value is (acc + bias) * scale, so
+    // the statistics follow from those of the accumulators, which are all still in registers here: an exact two-pass
+    // computation (sum over the wave's MT rows in registers, over the 16 pixels of a row by DPP, over the WM waves through
+    // LDS, all in a fixed order) BEFORE the store loop — it adds no live state to the loop below.
+    // mimo_group_norm_stats_slabs merges the tiles of an image (Chan's update, in double): the norm that consumes this
+    // tensor makes no statistics pass over HBM.  8x fewer partials than the 32-row slabs of mimo_conv2d_ext.
+    if constexpr (TSTATS) {
+      float* red = reinterpret_cast<float*>(lds);  // [2][WM][BN]; the patch images are dead once every wave is past its last step
+      float* red2 = red + WM * BN;
+      auto dpp = [](float v, auto ctrl_c) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+      };
+      auto row16_sum = [&](float x) {
+        x += dpp(x, IC<0xB1>{});   // quad_perm [1,0,3,2]
+        x += dpp(x, IC<0x4E>{});   // quad_perm [2,3,0,1]
+        x += dpp(x, IC<0x141>{});  // row_half_mirror
+        x += dpp(x, IC<0x140>{});  // row_mirror
+        return x;
+      };
+      const int colw = wn * 16 * NR + 4 * lg;  // this lane's first column inside the block's BN
+      auto tile_total = [&](const float* base, int ni) -> f32x4 {  // sum over the WM waves' partials, fixed order
+        f32x4 t = *reinterpret_cast<const f32x4*>(base + colw + ni * 16);
+#pragma unroll
+        for (int w = 1; w < WM; ++w) t += *reinterpret_cast<const f32x4*>(base + w * BN + colw + ni * 16);
+        return t;
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is past its last fragment read
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) {  // pass 1: sums
+        f32x4 t = acc[ni][0];
+#pragma unroll
+        for (int mi = 1; mi < MT; ++mi) t += acc[ni][mi];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = row16_sum(t[r]);
+        if (li == 0) *reinterpret_cast<f32x4*>(red + wm * BN + colw + ni * 16) = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) {  // pass 2: centred sums of squares
+        const f32x4 mean = tile_total(red, ni) * (1.0f / 256.0f);
+        f32x4 q = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const f32x4 d = acc[ni][mi] - mean;
+          q += d * d;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
+        if (li == 0) *reinterpret_cast<f32x4*>(red2 + wm * BN + colw + ni * 16) = q;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (wm == 0 && li == 0) {
+        const int64_t tile = ((int64_t)img * g.tiles_y + ty) * g.tiles_x + tx;
+        float* dst = g.tstats + tile * 2 * g.N;
+#pragma unroll
+        for (int ni = 0; ni < NR; ++ni) {
+          const int nn = N0 + colw + ni * 16;
+          if (nn < g.N) {
+            *reinterpret_cast<f32x4*>(dst + nn) = (tile_total(red, ni) * (1.0f / 256.0f) + bv[ni]) * g.out_scale;
+            *reinterpret_cast<f32x4*>(dst + g.N + nn) = tile_total(red2, ni) * (g.out_scale * g.out_scale);
+          }
+        }
+      }
+    }
     auto run = [&](auto has_res_c) {
       constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
 #pragma unroll
@@ -455,11 +521,14 @@ int launch_h(HArgs& g, hipStream_t st) {
   g.tiles_n = (g.N + bn - 1) / bn;
   const int64_t nwg = (int64_t)g.n * g.tiles_y * g.tiles_x * g.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-#define HC_LAUNCH(NR_, WM_, WN_, AB_)                                                                                      \
-  do {                                                                                                                   \
-    if (!g.ab) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, false, false>), dim3((unsigned)nwg), dim3(512), 0, st, g);     \
-    else if (g.raw) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true>), dim3((unsigned)nwg), dim3(512), 0, st, g); \
-    else hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false>), dim3((unsigned)nwg), dim3(512), 0, st, g);           \
+#define HC_LAUNCH(NR_, WM_, WN_, AB_)                                                                                                   \
+  do {                                                                                                                                \
+    const dim3 gr((unsigned)nwg), bl(512);                                                                                            \
+    if (!g.ab) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, false, false, false>), gr, bl, 0, st, g);                      \
+    else if (g.raw && g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, true>), gr, bl, 0, st, g);        \
+    else if (g.raw) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, false>), gr, bl, 0, st, g);                   \
+    else if (g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, true>), gr, bl, 0, st, g);                \
+    else hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, false>), gr, bl, 0, st, g);                             \
   } while (0)
   if (bn == 320) HC_LAUNCH(5, 2, 4, 7680);
   else if (bn == 256) HC_LAUNCH(4, 2, 4, 20480);
@@ -473,8 +542,8 @@ int launch_h(HArgs& g, hipStream_t st) {
 
 extern "C" int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const float* x2, int C2, const float* ab, int silu,
                                   const void* W, int64_t ldw, float* out, const mimo_hconv_params* p, const float* bias,
-                                  const float* img_bias, const float* residual, void* raw_out, float out_scale,
-                                  unsigned flags, void* stream) {
+                                  const float* img_bias, const float* residual, void* raw_out, float* tile_stats,
+                                  float out_scale, unsigned flags, void* stream) {
   if (!x1 || !W || !out || !p) return MIMO_EINVAL;
   if (p->n <= 0 || p->H <= 0 || p->W <= 0 || (p->H & 15) || (p->W & 15) || p->Cout <= 0 || (p->Cout & 3)) return MIMO_EINVAL;
   if (C1 <= 0 || C2 < 0 || (C2 > 0 && !x2)) return MIMO_EINVAL;
@@ -482,18 +551,19 @@ extern "C" int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const floa
   if ((C & 31) || (C2 > 0 && ((C1 & 63) || (C2 & 31)))) return MIMO_EINVAL;
   if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32)) return MIMO_EINVAL;
   if ((ab != nullptr) != (silu != 0)) return MIMO_EINVAL;  // instantiated: affine + SiLU (ResBlocks) | plain cast (Upsample)
-  if (raw_out && !ab) return MIMO_EINVAL;
+  if ((raw_out || tile_stats) && !ab) return MIMO_EINVAL;
+  if (tile_stats && (residual || (flags & MIMO_EPI_SILU))) return MIMO_EINVAL;  // statistics come from the accumulators: (acc + bias) * scale only
   if (!(flags & MIMO_EPI_OUT_F32) || (residual && !(flags & MIMO_EPI_RES_F32))) return MIMO_EINVAL;  // fp32 output / residual only
   if (p->upsample2x && ((p->H & 1) || (p->W & 1) || raw_out)) return MIMO_EINVAL;
   if (ldw < 9 * (int64_t)C || (ldw & 7)) return MIMO_EINVAL;
   if (!al16(x1) || (x2 && !al16(x2)) || !al16(W) || !al16(out) || (ab && !al16(ab)) || (residual && !al16(residual)) ||
-      (raw_out && !al16(raw_out)) || (bias && !al16(bias)) || (img_bias && !al16(img_bias)))
+      (raw_out && !al16(raw_out)) || (bias && !al16(bias)) || (img_bias && !al16(img_bias)) || (tile_stats && !al16(tile_stats)))
     return MIMO_EINVAL;
   const int ldib = p->img_bias_ld > 0 ? p->img_bias_ld : p->Cout;
   if (img_bias && (ldib & 3)) return MIMO_EINVAL;
   HArgs g{};
   g.x1 = x1; g.x2 = C2 > 0 ? x2 : nullptr; g.ab = ab; g.W = (const uint16_t*)W; g.out = out;
-  g.bias = bias; g.img_bias = img_bias; g.res = residual; g.raw = (uint16_t*)raw_out;
+  g.bias = bias; g.img_bias = img_bias; g.res = residual; g.raw = (uint16_t*)raw_out; g.tstats = tile_stats;
   g.ldw = ldw; g.ldib = ldib; g.C1 = C1; g.C2 = C2; g.n = p->n; g.H = p->H; g.Wd = p->W;
   g.ups = p->upsample2x ? 1 : 0;
   g.Hs = g.ups ? p->H / 2 : p->H; g.Ws = g.ups ? p->W / 2 : p->W;

@@ -225,7 +225,7 @@ __device__ __forceinline__ Moments merge(const Moments& a, const Moments& b) {
 }
 
 __global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, int C1, const float* cs2, int C2,
-                                                            int64_t slabs_per_img, int groups, int total, float eps,
+                                                            int64_t slabs_per_img, int rows_per_slab, int groups, int total, float eps,
                                                             float* stats) {
   const int ig = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, in
     const int c = c0 + (int)(i % cpg);
     const float* p = c < C1 ? cs1 + sl * 2 * C1 + c : cs2 + sl * 2 * C2 + (c - C1);
     const int Cx = c < C1 ? C1 : C2;
-    acc = merge(acc, Moments{32.0, (double)p[0], (double)p[Cx]});
+    acc = merge(acc, Moments{(double)rows_per_slab, (double)p[0], (double)p[Cx]});
   }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -508,15 +508,20 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
   return MIMO_OK;
 }
 
-extern "C" int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
-                                          int groups, float eps, float* stats, void* stream) {
-  if (!cs1 || !stats || n <= 0 || HW <= 0 || (HW & 31) || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
+extern "C" int mimo_group_norm_stats_slabs(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW, int rows_per_slab,
+                                           int groups, float eps, float* stats, void* stream) {
+  if (!cs1 || !stats || n <= 0 || HW <= 0 || rows_per_slab <= 0 || (HW % rows_per_slab) || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
   if ((C1 + C2) % groups || (C2 > 0 && !cs2)) return MIMO_EINVAL;
   const int total = n * groups;
   hipLaunchKernelGGL(gn_stats_cols_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cs1, C1,
-                     cs2, C2, HW >> 5, groups, total, eps, stats);
+                     cs2, C2, HW / rows_per_slab, rows_per_slab, groups, total, eps, stats);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
+}
+
+extern "C" int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
+                                          int groups, float eps, float* stats, void* stream) {
+  return mimo_group_norm_stats_slabs(cs1, C1, cs2, C2, n, HW, 32, groups, eps, stats, stream);
 }
 
 extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32,

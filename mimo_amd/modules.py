@@ -182,7 +182,7 @@ class ResnetBlock(HipModule):
             ab1 = ops.group_norm_affine(st1, p["g1"], p["be1"], self.in_channels, self.groups)
             # the half cast of the raw input (operand of the fused shortcut in conv2) leaves as a side output
             r = ops.conv3x3_fused(x, p["w1"], cout, x2=skip, ab=ab1, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
-                                  want_raw=fused_sc and not band, raw_dtype=ctx.dtype)
+                                  want_raw=fused_sc and not band, raw_dtype=ctx.dtype, tile_stats=True)
             h, raw = r if (fused_sc and not band) else (r, None)
         elif band:
             st1 = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)

@@ -391,11 +391,12 @@ def group_norm_stats(x1, *, groups=32, eps=1e-5, x2=None, dtype=None):
         assert _is_f32(x2) == f32 and x2.numel() // (n * C2) == HW
     cs1, cs2 = stats_of(x1), (None if x2 is None else stats_of(x2))
     stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
-    if cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 \
-            and cs1.shape[0] * 32 == n * HW and (cs2 is None or cs2.shape[0] == cs1.shape[0]):
-        # the producers' epilogues already reduced every 32-row slab: merge slabs x group columns, no pass over x
-        L.call("mimo_group_norm_stats_cols", cs1.data_ptr(), C1, _ptr(cs2), C2, n, HW, groups, float(eps),
-               stats.data_ptr(), _stream())
+    if cs1 is not None and (x2 is None or cs2 is not None) and (n * HW) % cs1.shape[0] == 0 \
+            and HW % ((n * HW) // cs1.shape[0]) == 0 and (cs2 is None or cs2.shape[0] == cs1.shape[0]):
+        # the producers' epilogues already reduced every slab (32 rows: mimo_gemm_ext / mimo_conv2d_ext column statistics;
+        # 256 pixels: mimo_conv3x3_fused tile statistics): merge slabs x group columns, no pass over x
+        L.call("mimo_group_norm_stats_slabs", cs1.data_ptr(), C1, _ptr(cs2), C2, n, HW, (n * HW) // cs1.shape[0], groups,
+               float(eps), stats.data_ptr(), _stream())
         return stats
     C = C1 + C2
     if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
@@ -465,6 +466,7 @@ def group_norm_affine(stats, gamma, beta, C, groups=32):
 # quantise worse than the row-tiled kernel's 192-row tiles (32 x 32 x 48 images x 640 channels = 384 blocks on 256 CUs).
 HCONV = True
 HCONV_MIN_HW = 4096
+HCONV_TILE_STATS = True   # conv3x3_fused(tile_stats=True) also emits per-tile GroupNorm statistics of its output
 
 
 def hconv_supported(x1, cout, *, x2=None, normed=True, upsample2x=False):
@@ -486,10 +488,12 @@ def hconv_supported(x1, cout, *, x2=None, normed=True, upsample2x=False):
 
 
 def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, imgs_per_bias_row=1, residual=None,
-                  out_scale=1.0, upsample2x=False, want_raw=False, raw_dtype=None, out=None):
+                  out_scale=1.0, upsample2x=False, want_raw=False, raw_dtype=None, out=None, tile_stats=False):
     """fp32 [n, H, W, cout] = epilogue(conv3x3(silu(x * a + b))) in ONE launch: x = fp32 virtual concat [x1 | x2], ab from
     group_norm_affine (None: plain cast, no SiLU — the up-sampling convolution); w = the packed weight of conv2d
-    (columns beyond 9 C, a fused shortcut segment, are ignored).  want_raw: also returns the half cast of x."""
+    (columns beyond 9 C, a fused shortcut segment, are ignored).  want_raw: also returns the half cast of x.
+    tile_stats: also emit the per-(16 x 16 tile, channel) statistics of `out` (attached as out._cs): the GroupNorm that
+    consumes `out` then merges them instead of making a statistics pass over the tensor."""
     _chk(x1, "x1")
     assert x1.dim() == 4 and x1.is_contiguous() and x1.dtype == torch.float32 and w.is_contiguous()
     n, Hs, Ws, C1 = x1.shape
@@ -516,6 +520,8 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
         ldib = img_bias.stride(0)
     p = L.HconvParams(n, H, W, cout, int(upsample2x), imgs_per_bias_row, ldib)
+    ts = torch.empty((n * (H // 16) * (W // 16), 2, cout), device=x1.device, dtype=torch.float32) \
+        if (tile_stats and HCONV_TILE_STATS and residual is None and ab is not None) else None
     fl = 2 * n * H * W * cout * 9 * C
     _count(fl)
     with _Bracket("gemm_kernel", fl, _nbytes(x1, x2, out, residual, raw) + cout * 9 * C * w.element_size(),
@@ -523,7 +529,8 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
                   f"{' gn' if ab is not None else ''}{' raw' if want_raw else ''} n{n}"):
         L.call("mimo_conv3x3_fused", dt_code(w.dtype), x1.data_ptr(), C1, _ptr(x2), C2, _ptr(ab), int(ab is not None),
                w.data_ptr(), w.shape[1], out.data_ptr(), ctypes.byref(p), _ptr(bias), _ptr(img_bias), _ptr(residual), _ptr(raw),
-               float(out_scale), flags, _stream())
+               _ptr(ts), float(out_scale), flags, _stream())
+    with_stats(out, ts)
     return (out, raw) if want_raw else out
 
 

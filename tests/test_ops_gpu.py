@@ -280,6 +280,19 @@ def test_conv3x3_fused_groupnorm_silu(dev, dtype, case):
         g = 2 if n % 2 == 0 else 1
         out3 = ops.conv3x3_fused(x1, wp, cout, x2=x2, ab=ab, img_bias=temb[: n // g], imgs_per_bias_row=g, upsample2x=ups)
         assert rel_l2(out3, ref0 + temb[: n // g].repeat_interleave(g, 0)[:, None, None, :]) < tol
+    if gn and cout % 32 == 0:
+        # tile statistics of the output (per 16 x 16 tile and channel, from the epilogue) merge to the GroupNorm statistics a
+        # pass over the tensor computes; the output itself is the same bits with and without them
+        o_ts = ops.conv3x3_fused(x1, wp, cout, x2=x2, ab=ab, bias=b, img_bias=temb, out_scale=0.5, tile_stats=True)
+        o_pl = ops.conv3x3_fused(x1, wp, cout, x2=x2, ab=ab, bias=b, img_bias=temb, out_scale=0.5)
+        assert ops.stats_of(o_ts) is not None and ops.stats_of(o_ts).shape == (n * (H // 16) * (W // 16), 2, cout)
+        assert torch.equal(o_ts, o_pl)
+        st_merge = ops.group_norm_stats(o_ts, groups=32, eps=1e-5, dtype=dtype)
+        st_pass = ops.group_norm_stats(o_pl, groups=32, eps=1e-5, dtype=dtype)
+        ref_mean = o_pl.view(n, H * W, 32, cout // 32).double().mean(dim=(1, 3))
+        ref_var = o_pl.view(n, H * W, 32, cout // 32).double().var(dim=(1, 3), unbiased=False)
+        assert float((st_merge[..., 0].double() - ref_mean).abs().max()) < 1e-5 * (1 + float(ref_mean.abs().max()))
+        assert rel_l2(st_merge[..., 1], (ref_var + 1e-5).rsqrt()) < 1e-5 and rel_l2(st_pass[..., 1], st_merge[..., 1]) < 1e-5
     one = ops.conv3x3_fused(x1[-1:].contiguous(), pack_conv(w, dtype), cout, x2=None if x2 is None else x2[-1:].contiguous(),
                             ab=None if ab is None else ab[-1:].contiguous(), upsample2x=ups)
     assert torch.equal(one, out[-1:])

@@ -22,10 +22,14 @@ def main():
     dev = torch.device("cuda:0")
     pipe = bench.build_pipeline(dev, torch.float16)
     best = [None] * len(settings)
+    defaults = {k: getattr(ops, k) for st in settings for k in st}
     for rnd in range(3):
         for i, st in enumerate(settings):
+            for k, v in defaults.items():  # every knob any setting touches starts from its default
+                setattr(ops, k, v)
             for k, v in st.items():
-                setattr(ops, k, type(getattr(ops, k))(v))
+                cur = defaults[k]
+                setattr(ops, k, (v not in ("0", "false", "False", "")) if isinstance(cur, bool) else type(cur)(v))
             t, fl, n, fam = bench.measure_forward(pipe, dev, torch.float16, size, iters=3)
             if best[i] is None or t < best[i][0]:
                 best[i] = (t, n, fam)

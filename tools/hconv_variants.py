@@ -115,7 +115,7 @@ def main():
                 rc = lb.mimo_conv3x3_fused(ops.dt_code(dt), x1.data_ptr(), C1, None if x2 is None else x2.data_ptr(), C2,
                                            None if ab is None else ab.data_ptr(), int(ab is not None), w.data_ptr(), w.shape[1],
                                            out.data_ptr(), ctypes.byref(p), b.data_ptr(), None, None,
-                                           None if raw is None else raw.data_ptr(), 1.0, L.EPI_OUT_F32, st)
+                                           None if raw is None else raw.data_ptr(), None, 1.0, L.EPI_OUT_F32, st)
                 assert rc == 0, rc
             return f
         fns = [mk(lb) for lb in libs]

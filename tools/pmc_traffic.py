@@ -19,7 +19,8 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        fam = "gemm_kernel" if ("gemm_kernel" in k or "gemm_dense_persist_kernel" in k or "gemm_stream_kernel" in k or "splitk_reduce" in k) else \
+        fam = "gemm_kernel" if ("gemm_kernel" in k or "gemm_dense_persist_kernel" in k or "gemm_stream_kernel" in k or "splitk_reduce" in k
+                                or "hconv_kernel" in k or "ff_fused_kernel" in k) else \
               "attn_kernel" if ("attn_kernel" in k or "attn40_kernel" in k) and "temporal" not in k else None
         if fam:
             tot[fam] += float(r["Counter_Value"])
