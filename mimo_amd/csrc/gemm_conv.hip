@@ -1088,6 +1088,166 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
   MIMO_TRACE_REAL(g, tr, 0xff);
 }
 
+// Dense GEMM, 256 x 256 x 64 tile, EIGHT phases per pair of K-tiles with the two wave groups half a phase apart
+// (cdna_hip_programming.md, "The 256^2 8-phase template"): 8 waves = 2 (M) x 4 (N), each 128 x 64 of the tile (128 accumulator
+// registers).  A K-tile is four phases, one 64 x 32 quadrant of the wave's output each (16 MFMAs):
+//   LOAD segment: ds_read the quadrant's operand sub-tile that is not in registers yet (8 A | 4 B fragments), issue the
+//                 LDS-DMAs of ONE half-tile (128 rows x 64) of a K-tile ahead, lgkmcnt(0), barrier
+//   MFMA segment: 16 MFMAs at raised priority, barrier
+// Waves 0-3 (group 0) and 4-7 (group 1, its SIMD partners) run ONE barrier apart: while a group multiplies, the other one
+// reads LDS and issues DMAs, so a SIMD's matrix pipe sees MFMAs from one wave at a time and the partner's load segment
+// hides under them.  LDS = 8 half-tile slots of 16 KB (K-tile parity x {A, B} x half); DMAs are counted (vmcnt(4) once
+// per K-tile, never 0 in the loop).  Slot hand-off (reads of a phase are complete before its barrier):
+//   B halves of K-tile t+1 are staged in phases 0, 1 of K-tile t (their slots were last read in phase 3 of t-1),
+//   A halves of K-tile t+2 in phase 3 of t (A sub-tiles are read in phases 0 and 2 only), followed by the wait that
+//   retires everything K-tile t+1 needs; the first reads of t+1 come two barriers later in either group.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
+  constexpr int NR = 4, MT = 8, BM = 256, BN = 256, HTB = 16384;  // HTB: bytes of a half-tile
+  __shared__ __attribute__((aligned(16))) uint4 smem[8 * HTB / 16];
+  char* const lds = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = (int)(wave_u >> 2), wc = (int)(wave_u & 3u);
+  const int lg = lane >> 4, li = lane & 15;
+  const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t M0 = (int64_t)(L / (unsigned)g.tiles_n) * BM;
+  const int N0 = (int)(L % (unsigned)g.tiles_n) * BN;
+  const int nkt = g.nkt;  // even (host)
+
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  // one descriptor per half-tile row range, clipped to the rows that exist (rows beyond M / N are zero-filled)
+  i32x4 rA[2], rB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t ra = g.M - (M0 + 128 * h), rb = (int64_t)g.N - (N0 + 128 * h);
+    const int64_t va = ra < 0 ? 0 : (ra > 128 ? 128 : ra), vb = rb < 0 ? 0 : (rb > 128 ? 128 : rb);
+    rA[h] = make_rsrc(g.A + (M0 + 128 * h) * g.lda, va > 0 ? (unsigned)(((va - 1) * g.lda + g.K) * 2) : 0u);
+    rB[h] = make_rsrc(g.W + ((int64_t)N0 + 128 * h) * g.ldw, vb > 0 ? (unsigned)(((vb - 1) * g.ldw + g.K) * 2) : 0u);
+  }
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+  // staging role: thread -> row (tid >> 3) (+ 64 for the second DMA), physical chunk tid & 7 = logical chunk ^ (row & 7)
+  const unsigned srow = (unsigned)tid >> 3, lc = ((unsigned)tid & 7u) ^ (srow & 7u);
+  const unsigned av = srow * (unsigned)(g.lda * 2) + lc * 16u, bv = srow * (unsigned)(g.ldw * 2) + lc * 16u;
+  const unsigned a64 = (unsigned)(g.lda * 128), b64 = (unsigned)(g.ldw * 128);  // bytes of 64 rows
+  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+                 : "memory", "m0");
+  };
+  // half-tile (operand o, half h) of K-tile kt into parity d: two DMAs per thread
+  auto stage = [&](int o, int h, int kt, int d) {
+    i32x4 r = o ? rB[h] : rA[h];
+    r.z = kt < nkt ? r.z : 0;  // past the end: zero fill keeps the DMA counts uniform
+    const unsigned soff = kt < nkt ? (unsigned)kt * 128u : 0u;
+    const unsigned base = smem_base + (unsigned)(((d * 2 + o) * 2 + h) * HTB) + wave_u * 1024u;
+    dma(r, o ? bv : av, soff, base);
+    dma(r, o ? bv : av, soff + (o ? b64 : a64), base + 8192u);
+  };
+  // fragment bases: row li of a 16-row tile, chunk (4 kh + lg) ^ (li & 7); the wave's half-tile and column offset folded in
+  unsigned ab[2][2], bb[2][2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const unsigned ch = (unsigned)((4 * kh + lg) ^ (li & 7));
+      ab[d][kh] = (unsigned)(((d * 2 + 0) * 2 + wr) * HTB) + (unsigned)li * 128u + ch * 16u;
+      bb[d][kh] = (unsigned)(((d * 2 + 1) * 2 + (wc >> 1)) * HTB) + (unsigned)(((wc & 1) * 64 + li) * 128) + ch * 16u;
+    }
+
+  f32x4 acc[NR][MT];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 fa[4][2], fb[2][2];
+  auto read_a = [&](auto d_c, int mq) {
+    constexpr int D = decltype(d_c)::value;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi][kh] = *reinterpret_cast<const uint4*>(lds + ab[D][kh] + (mq * 64 + mi * 16) * 128);
+  };
+  auto read_b = [&](auto d_c, int nq) {
+    constexpr int D = decltype(d_c)::value;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fb[ni][kh] = *reinterpret_cast<const uint4*>(lds + bb[D][kh] + (nq * 32 + ni * 16) * 128);
+  };
+  auto mfmas = [&](auto mq_c, auto nq_c) {
+    constexpr int MQ = decltype(mq_c)::value, NQ = decltype(nq_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[NQ * 2 + ni][MQ * 4 + mi] = HT<DT>::mfma16(fb[ni][kh], fa[mi][kh], acc[NQ * 2 + ni][MQ * 4 + mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the end of a LOAD segment: this wave's fragment reads are complete BEFORE the barrier (a slot may be re-staged by the
+  // other group right after it), and nothing is scheduled across
+  auto seg_end = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+  };
+
+  // ---- prologue: K-tile 0 complete, the A halves of K-tile 1 in flight ----
+  stage(0, 0, 0, 0); stage(0, 1, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0);
+  stage(0, 0, 1, 1); stage(0, 1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind group 0 from here on
+
+  auto ktile = [&](auto d_c, int t) {
+    constexpr int D = decltype(d_c)::value;
+    // phase 0: quadrant (m0, n0)
+    read_b(d_c, 0);
+    read_a(d_c, 0);
+    stage(1, 0, t + 1, D ^ 1);
+    seg_end();
+    mfmas(IC<0>{}, IC<0>{});
+    mfma_end();
+    // phase 1: (m0, n1)
+    read_b(d_c, 1);
+    stage(1, 1, t + 1, D ^ 1);
+    seg_end();
+    mfmas(IC<0>{}, IC<1>{});
+    mfma_end();
+    // phase 2: (m1, n1)
+    read_a(d_c, 1);
+    seg_end();
+    mfmas(IC<1>{}, IC<1>{});
+    mfma_end();
+    // phase 3: (m1, n0); the A slots of this parity are free (last read in phase 2): K-tile t + 2 moves in
+    read_b(d_c, 0);
+    stage(0, 0, t + 2, D);
+    stage(0, 1, t + 2, D);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything K-tile t + 1 needs has landed (this wave's part)
+    seg_end();
+    mfmas(IC<1>{}, IC<0>{});
+    mfma_end();
+  };
+  for (int t = 0; t < nkt; t += 2) {
+    ktile(IC<0>{}, t);
+    ktile(IC<1>{}, t + 1);
+  }
+  if (wr == 0) asm volatile("s_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs must not outlive the block's LDS
+  tile_epilogue<DT, NR, MT, BM, true>(g, acc, M0, N0, wr, wc, lg, li, 0u);
+}
+
 // Split-K reduction + the full epilogue: out = epi(sum_s partial[s]); one thread per 4 consecutive columns.
 template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, int splits) {
@@ -1309,10 +1469,26 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   return MIMO_OK;
 }
 
+// MIMO_GEMM_8P (tune build; the shipped default is the constant below): 1 = dense GEMMs with an even number of K-tiles
+// and enough 256 x 256 tiles take the 8-phase kernel
+constexpr int GEMM_8P_DEFAULT = 1;
+
 template <int DT, int MODE>
 int launch(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   const bool geglu = g.flags & MIMO_EPI_GEGLU;
+  if constexpr (MODE == 0) {
+    const int p8 = tune_env("MIMO_GEMM_8P", GEMM_8P_DEFAULT);
+    const int64_t tn8 = (g.N + 255) / 256, nt8 = ((g.M + 255) / 256) * tn8;
+    // (N = 640 is 2.5 tiles of 256: a sixth of the columns would be padding — those shapes keep the 320-wide tiles)
+    const bool n_fits = tn8 * 256 - g.N <= g.N / 12;
+    if (p8 && !g.colstats && !g.ln_out && (g.K % 128) == 0 && n_fits && nt8 >= 128 && nt8 <= 0x7fffffff && g.M < 0x7fffffff) {
+      g.tiles_n = (int)tn8;
+      hipLaunchKernelGGL((gemm8_kernel<DT>), dim3((unsigned)nt8), dim3(512), 0, st, g);
+      MIMO_LAUNCH_CHECK();
+      return MIMO_OK;
+    }
+  }
   // NR = 5 (BN = 160) divides every SD1.5 width (320/640/960/1280/1920/2560); NR = 4 otherwise
   if (!geglu && (g.N % 160 == 0)) return launch_nr<DT, MODE, 5>(g, st);
   return launch_nr<DT, MODE, 4>(g, st);
