@@ -4,6 +4,8 @@ Each setting is timed three times, interleaved; prints the per-setting best and 
 import os
 import sys
 
+if any(a.startswith("env:") or ",env:" in a for a in sys.argv[1:]):  # environment knobs exist in the tune build only
+    os.environ.setdefault("MIMO_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimo_amd", "libmimo_hip_tune.so"))
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,12 +24,18 @@ def main():
     dev = torch.device("cuda:0")
     pipe = bench.build_pipeline(dev, torch.float16)
     best = [None] * len(settings)
-    defaults = {k: getattr(ops, k) for st in settings for k in st}
+    defaults = {k: getattr(ops, k) for st in settings for k in st if not k.startswith("env:")}
+    env_keys = {k[4:] for st in settings for k in st if k.startswith("env:")}
     for rnd in range(3):
         for i, st in enumerate(settings):
             for k, v in defaults.items():  # every knob any setting touches starts from its default
                 setattr(ops, k, v)
+            for k in env_keys:
+                os.environ.pop(k, None)
             for k, v in st.items():
+                if k.startswith("env:"):  # e.g. env:MIMO_GEMM_8P=0 (read by the tune library at every launch)
+                    os.environ[k[4:]] = v
+                    continue
                 cur = defaults[k]
                 setattr(ops, k, (v not in ("0", "false", "False", "")) if isinstance(cur, bool) else type(cur)(v))
             t, fl, n, fam = bench.measure_forward(pipe, dev, torch.float16, size, iters=3)
