@@ -175,10 +175,11 @@ int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int C2, int x_
 int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
                                int groups, float eps, float* stats, void* stream);
 /* The same merge for partials over `rows_per_slab` pixels each (HW % rows_per_slab == 0): 32 = the column statistics of
- * mimo_gemm_ext / mimo_conv2d_ext, 256 = the tile statistics of mimo_conv3x3_fused.  Both sources of a virtual concat must
- * use the same slab size and slab order (image-major). */
-int mimo_group_norm_stats_slabs(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW, int rows_per_slab,
-                                int groups, float eps, float* stats, void* stream);
+ * mimo_gemm_ext / mimo_conv2d_ext / the fused tails / mimo_conv3x3_fused with a residual, 256 = the tile statistics of
+ * mimo_conv3x3_fused without one.  The two sources of a virtual concat may use different slab sizes (rows_per_slab2 is
+ * ignored when C2 = 0); slabs are image-major, any pixel order inside an image. */
+int mimo_group_norm_stats_slabs(const float* cs1, int C1, int rows_per_slab1, const float* cs2, int C2, int rows_per_slab2,
+                                int n, int64_t HW, int groups, float eps, float* stats, void* stream);
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);
@@ -252,10 +253,15 @@ int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* W1, const f
 /* The same with the block's output projection and its residual folded in (the end of Transformer3DModel.forward,
  * src/models/transformer_3d.py:150-169, and of TemporalTransformer3DModel.forward, src/models/motion_module.py:170-184):
  *   out[M, C] (fp32) = x[M, C] (fp32, the block input) + (residual + FF(A)) @ Wp^T + bp
- *   Wp: half16 [C, C] = proj_out.weight with rows in tile order and the K axis permuted (mimo_amd.packing.pack_proj_tail). */
+ *   Wp: half16 [C, C] = proj_out.weight with rows in tile order and the K axis permuted (mimo_amd.packing.pack_proj_tail).
+ *   colstats: NULL, or fp32 [M / 32, 2, C] (M % 32 == 0): the launch also writes the GroupNorm column statistics of `out`
+ *   per 32-row slab — (mean, sum of squared deviations) per column, the layout of mimo_epilogue_ext.colstats — from the
+ *   values in registers, so the GroupNorm that consumes `out` (src/models/motion_module.py:156, src/models/resnet.py:217)
+ *   makes no statistics pass; merge with mimo_group_norm_stats_slabs(rows_per_slab = 32). */
 int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
                        const float* b2, const float* residual, int64_t ldr, const void* Wp, const float* bp,
-                       const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C, void* stream);
+                       const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C, float* colstats,
+                       void* stream);
 /* The whole tail of a transformer block after its attention core in one launch: the attention output projection with its
  * residual (+ the collapsed cross-attention as a per-image vector), the LayerNorm in front of the feed-forward, the
  * feed-forward and the owning transformer's proj_out with its residual (BasicTransformerBlock.forward after attn1,
@@ -266,12 +272,12 @@ int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, co
  *   O: half16 attention output; Wstream: half16 [10 C, C] = [Wo with rows in tile order (pack_rows_tail) | W1 GEGLU-packed
  *   with its K axis permuted (pack_ff2_kperm) | Wp as for mimo_ff_proj_fused] (mimo_amd.packing.pack_block_tail_stream);
  *   y and n never reach memory.  img_bias: fp32 [ceil(M / rows_per_img), ldib] or NULL, rows_per_img >= 128.
- *   MIMO_EINVAL unless C == 320. */
+ *   colstats: as for mimo_ff_proj_fused.  MIMO_EINVAL unless C == 320. */
 int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* Wstream, const float* bo,
                           const float* img_bias, int64_t ldib, int64_t rows_per_img, const float* residual, int64_t ldr,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1, const void* W2,
                           const float* b2, const float* bp, const float* x, int64_t ldx, float* out, int64_t ldo,
-                          int64_t M, int C, void* stream);
+                          int64_t M, int C, float* colstats, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional

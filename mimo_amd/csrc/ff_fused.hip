@@ -52,6 +52,7 @@ struct FFArgs {
   const float* x;       // fp32 [M, ldx]: the block input (the residual of proj_out)
   float* out32;         // fp32 [M, ldo32]
   int64_t ldx, ldo32;
+  float* colstats;      // MODE >= 1, optional: fp32 [M / 32, 2, C] GroupNorm column statistics of out32 per 32-row slab (as mimo_gemm_ext)
   // MODE = 2: the attention output projection and the LayerNorm in front of the feed-forward folded in as well:
   //   y = res + A @ Wo^T + bo (+ img_bias[row / rows_per_img]);  n = LayerNorm(y) * gamma + beta;  out32 = x + (y + FF(n)) @ Wp^T + bp
   // (A = the attention output, res = the stream before the attention; W1 then carries the K permutation of pack_ff2_kperm)
@@ -540,6 +541,40 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         for (int mi = 0; mi < 2; ++mi)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
                                                  o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, 0);
+      // ---- optional: GroupNorm column statistics of out32, per 32-row slab = exactly this wave's rows: (mean, sum of squared
+      // deviations from that mean) per column, an exact two-pass computation on the values still in registers (sum over the two
+      // row tiles, then over the 16 rows of a tile by DPP, fixed order), in the layout of mimo_gemm_ext's colstats.  The norm
+      // that consumes out32 (the motion module's / the next ResBlock's GroupNorm) then makes no statistics pass over HBM. ----
+      if (g.colstats) {
+        auto dpp = [](float v, auto ctrl_c) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+        };
+        auto row16_sum = [&](float v) {
+          v += dpp(v, ICf<0xB1>{});   // quad_perm [1,0,3,2]
+          v += dpp(v, ICf<0x4E>{});   // quad_perm [2,3,0,1]
+          v += dpp(v, ICf<0x141>{});  // row_half_mirror
+          v += dpp(v, ICf<0x140>{});  // row_mirror
+          return v;
+        };
+        // (one lane-dependent offset made inside the panel loop from values that are live anyway; the panel's slab base and
+        // the number of valid slabs travel in the buffer descriptor: a slab beyond M is dropped by the range check)
+        const __amdgpu_buffer_rsrc_t rCS = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.colstats + (M0 >> 5) * 2 * C), 0, (int)(((rows_valid + 31) >> 5) * 2 * C * 4), 0x00020000);
+        const unsigned cs_off = pinned(li == 0 ? (unsigned)((pr * 2 * C + 160 * sh + 4 * lg) * 4) : 0x80000000u);
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt) {
+          f32x4 s = acc2[nt][0] + acc2[nt][1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r] = row16_sum(s[r]);
+          const f32x4 mean = s * (1.0f / 32.0f);
+          const f32x4 d0 = acc2[nt][0] - mean, d1 = acc2[nt][1] - mean;
+          f32x4 q = d0 * d0 + d1 * d1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean), rCS, cs_off + 64u * (unsigned)nt, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rCS, cs_off + 64u * (unsigned)nt, (unsigned)(C * 4), 0);
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
@@ -593,8 +628,10 @@ extern "C" int mimo_ff_fused(int dtype, const void* A, int64_t lda, const void* 
 
 extern "C" int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, const float* b1, const void* W2,
                                   const float* b2, const float* residual, int64_t ldr, const void* Wp, const float* bp,
-                                  const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C_, void* stream) {
+                                  const float* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int C_, float* colstats,
+                                  void* stream) {
   if (!A || !W1 || !W2 || !residual || !Wp || !x || !out || M <= 0) return MIMO_EINVAL;
+  if (colstats && ((M & 31) || !aligned16(colstats))) return MIMO_EINVAL;
   if (C_ != C) return MIMO_EINVAL;
   if ((lda & 7) || (ldr & 3) || (ldx & 3) || (ldo & 3) || !aligned16(A) || !aligned16(W1) || !aligned16(W2) || !aligned16(residual) ||
       !aligned16(Wp) || !aligned16(x) || !aligned16(out))
@@ -605,7 +642,7 @@ extern "C" int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const v
   FFArgs g{};
   g.A = (const uint16_t*)A; g.W1 = (const uint16_t*)W1; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
   g.lda = lda; g.ldr = ldr; g.M = M;
-  g.Wp = (const uint16_t*)Wp; g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo;
+  g.Wp = (const uint16_t*)Wp; g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo; g.colstats = colstats;
   return ff_launch(dtype, g, 1, stream);
 }
 
@@ -613,8 +650,9 @@ extern "C" int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, c
                                      const float* img_bias, int64_t ldib, int64_t rows_per_img, const float* residual,
                                      int64_t ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1,
                                      const void* W2, const float* b2, const float* bp, const float* x, int64_t ldx,
-                                     float* out, int64_t ldo, int64_t M, int C_, void* stream) {
+                                     float* out, int64_t ldo, int64_t M, int C_, float* colstats, void* stream) {
   if (!O || !Wstream || !residual || !ln_gamma || !ln_beta || !W2 || !x || !out || M <= 0) return MIMO_EINVAL;
+  if (colstats && ((M & 31) || !aligned16(colstats))) return MIMO_EINVAL;
   if (C_ != C) return MIMO_EINVAL;
   if (img_bias && (rows_per_img < BM || (ldib & 3) || !aligned16(img_bias))) return MIMO_EINVAL;  // (<= two images per panel)
   if ((ldo_in & 7) || (ldr & 3) || (ldx & 3) || (ldo & 3) || !aligned16(O) || !aligned16(Wstream) || !aligned16(W2) ||
@@ -627,7 +665,7 @@ extern "C" int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, c
   FFArgs g{};
   g.A = (const uint16_t*)O; g.W1 = (const uint16_t*)Wstream; g.W2 = (const uint16_t*)W2; g.b1 = b1; g.b2 = b2; g.res = residual;
   g.lda = ldo_in; g.ldr = ldr; g.M = M;
-  g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo;
+  g.bp = bp; g.x = x; g.out32 = out; g.ldx = ldx; g.ldo32 = ldo; g.colstats = colstats;
   g.bo = bo; g.img_bias = img_bias; g.ldib = ldib; g.rows_per_img = img_bias ? rows_per_img : 1;
   g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps;
   return ff_launch(dtype, g, 2, stream);

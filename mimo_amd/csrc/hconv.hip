@@ -76,7 +76,7 @@ constexpr unsigned OOBA = 0x80000000u;  // every descriptor is < 2 GiB: OOBA (+ 
 constexpr int PB = 18 * 24 * 64;        // bytes of one patch image: 18 rows x 24-pixel pitch x 32 half channels
 constexpr int STG = 16384;              // staging bytes of one patch pass: 512 threads x 2 x 16 B
 
-template <int DT, int NR, int WM, int WN, int ABMAX, bool NORM, bool SIDE, bool TSTATS>
+template <int DT, int NR, int WM, int WN, int ABMAX, bool NORM, bool SIDE, int TSTATS>
 __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
   static_assert(WM * WN == 8, "8 waves");
   constexpr int MT = 16 / WM;       // tile rows (= 16-pixel MFMA column tiles) per wave
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     // LDS, all in a fixed order) BEFORE the store loop — it adds no live state to the loop below.
     // mimo_group_norm_stats_slabs merges the tiles of an image (Chan's update, in double): the norm that consumes this
     // tensor makes no statistics pass over HBM.  8x fewer partials than the 32-row slabs of mimo_conv2d_ext.
-    if constexpr (TSTATS) {
+    if constexpr (TSTATS == 1) {
       float* red = reinterpret_cast<float*>(lds);  // [2][WM][BN]; the patch images are dead once every wave is past its last step
       float* red2 = red + WM * BN;
       auto dpp = [](float v, auto ctrl_c) {
@@ -469,6 +469,60 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
     }
     auto run = [&](auto has_res_c) {
       constexpr bool HAS_RES = decltype(has_res_c)::value != 0;
+      if constexpr (TSTATS == 2) {
+        // ---- store loop with GroupNorm statistics of the stored values (residual included), per 32-pixel slab = two image
+        // rows of the tile, both owned by this wave: an exact two-pass computation on the final values of the pair (sum over
+        // the two rows in registers, over the 16 pixels of a row by DPP), the layout and slab size of mimo_gemm_ext's
+        // column statistics (slabs of an image are contiguous: tile * 8 + row pair) ----
+        auto dpp = [](float v, auto ctrl_c) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+        };
+        auto row16_sum = [&](float x) {
+          x += dpp(x, IC<0xB1>{});
+          x += dpp(x, IC<0x4E>{});
+          x += dpp(x, IC<0x141>{});
+          x += dpp(x, IC<0x140>{});
+          return x;
+        };
+        const int64_t tile = ((int64_t)img * g.tiles_y + ty) * g.tiles_x + tx;
+        float* const sdst = g.tstats + (tile * 8 + wm * (MT / 2)) * 2 * g.N + N0 + wn * 16 * NR + 4 * lg;
+#pragma unroll
+        for (int sp = 0; sp < MT / 2; ++sp) {
+          const unsigned prow_a = (unsigned)(((wm * MT + 2 * sp) * g.Wd + li) * g.N), prow_b = prow_a + (unsigned)(g.Wd * g.N);
+          f32x4 ra[NR], rb[NR];
+          if (HAS_RES) {
+#pragma unroll
+            for (int ni = 0; ni < NR; ++ni) {
+              const unsigned c = (unsigned)(N0 + wn * 16 * NR + ni * 16 + 4 * lg);
+              ra[ni] = ld4(r_res, col_ok[ni] ? (prow_a + c) * 4u : OOB);
+              rb[ni] = ld4(r_res, col_ok[ni] ? (prow_b + c) * 4u : OOB);
+            }
+          }
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) {
+            f32x4 va = acc[ni][2 * sp] + bv[ni], vb = acc[ni][2 * sp + 1] + bv[ni];
+            if (HAS_RES) { va += ra[ni]; vb += rb[ni]; }
+            va *= g.out_scale;
+            vb *= g.out_scale;
+            const unsigned c = (unsigned)(N0 + wn * 16 * NR + ni * 16 + 4 * lg);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va), r_out, col_ok[ni] ? (prow_a + c) * 4u : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), r_out, col_ok[ni] ? (prow_b + c) * 4u : OOB, 0, 0);
+            f32x4 t = va + vb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = row16_sum(t[r]);
+            const f32x4 mean = t * (1.0f / 32.0f);
+            const f32x4 d0 = va - mean, d1 = vb - mean;
+            f32x4 q = d0 * d0 + d1 * d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
+            if (li == 0 && col_ok[ni]) {
+              *reinterpret_cast<f32x4*>(sdst + (int64_t)sp * 2 * g.N + ni * 16) = mean;
+              *reinterpret_cast<f32x4*>(sdst + (int64_t)sp * 2 * g.N + g.N + ni * 16) = q;
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const unsigned prow = (unsigned)(((wm * MT + mi) * g.Wd + li) * g.N);
@@ -492,7 +546,8 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HArgs g) {
         }
       }
     };
-    if (g.res) run(IC<1>{});
+    if constexpr (TSTATS == 2) run(IC<1>{});  // (launched with a residual only)
+    else if (g.res) run(IC<1>{});
     else run(IC<0>{});
   }
 }
@@ -524,11 +579,13 @@ int launch_h(HArgs& g, hipStream_t st) {
 #define HC_LAUNCH(NR_, WM_, WN_, AB_)                                                                                                   \
   do {                                                                                                                                \
     const dim3 gr((unsigned)nwg), bl(512);                                                                                            \
-    if (!g.ab) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, false, false, false>), gr, bl, 0, st, g);                      \
-    else if (g.raw && g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, true>), gr, bl, 0, st, g);        \
-    else if (g.raw) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, false>), gr, bl, 0, st, g);                   \
-    else if (g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, true>), gr, bl, 0, st, g);                \
-    else hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, false>), gr, bl, 0, st, g);                             \
+    if (!g.ab && g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, false, false, 1>), gr, bl, 0, st, g);             \
+    else if (!g.ab) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, false, false, 0>), gr, bl, 0, st, g);                    \
+    else if (g.raw && g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, 1>), gr, bl, 0, st, g);          \
+    else if (g.raw) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, true, 0>), gr, bl, 0, st, g);                      \
+    else if (g.tstats && g.res) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, 2>), gr, bl, 0, st, g);         \
+    else if (g.tstats) hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, 1>), gr, bl, 0, st, g);                  \
+    else hipLaunchKernelGGL((hconv_kernel<DT, NR_, WM_, WN_, AB_, true, false, 0>), gr, bl, 0, st, g);                                \
   } while (0)
   if (bn == 320) HC_LAUNCH(5, 2, 4, 7680);
   else if (bn == 256) HC_LAUNCH(4, 2, 4, 20480);
@@ -551,8 +608,10 @@ extern "C" int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const floa
   if ((C & 31) || (C2 > 0 && ((C1 & 63) || (C2 & 31)))) return MIMO_EINVAL;
   if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32)) return MIMO_EINVAL;
   if ((ab != nullptr) != (silu != 0)) return MIMO_EINVAL;  // instantiated: affine + SiLU (ResBlocks) | plain cast (Upsample)
-  if ((raw_out || tile_stats) && !ab) return MIMO_EINVAL;
-  if (tile_stats && (residual || (flags & MIMO_EPI_SILU))) return MIMO_EINVAL;  // statistics come from the accumulators: (acc + bias) * scale only
+  if (raw_out && !ab) return MIMO_EINVAL;
+  // statistics: per 256-pixel tile from the accumulators ((acc + bias) * scale: no residual), or per 32-pixel slab from the
+  // stored values when a residual is added (instantiated for the ResBlock's second convolution: affine, no side output)
+  if (tile_stats && ((flags & MIMO_EPI_SILU) || (residual && (!ab || raw_out)))) return MIMO_EINVAL;
   if (!(flags & MIMO_EPI_OUT_F32) || (residual && !(flags & MIMO_EPI_RES_F32))) return MIMO_EINVAL;  // fp32 output / residual only
   if (p->upsample2x && ((p->H & 1) || (p->W & 1) || raw_out)) return MIMO_EINVAL;
   if (ldw < 9 * (int64_t)C || (ldw & 7)) return MIMO_EINVAL;

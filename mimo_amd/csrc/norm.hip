@@ -210,46 +210,50 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const void* x1, int C1
 
 // ---------------------------------------------------------------------------------
 // GroupNorm statistics from epilogue column statistics (mimo_epilogue_ext.colstats of the producing GEMM /
-// convolution): cs[slab][0][c] = mean, cs[slab][1][c] = sum of squared deviations of the slab's 32 rows of column c.
-// One wave per (image, group) merges (slabs of the image) x (columns of the group) with Chan's parallel update
-// in double; lane-sequential, then a fixed xor butterfly: the result depends on the data only.
+// convolution): cs[slab][0][c] = mean, cs[slab][1][c] = sum of squared deviations of the slab's rows of column c.
+// One block per (image, group) merges (slabs of the image) x (columns of the group) in two passes over the partials
+// (which sit in L2): the count-weighted mean of the slab means, then sum(m2_i + rows_i * (mean_i - mean)^2) — the
+// pairwise update of Chan et al. summed in closed form, no division per item; double accumulators, a fixed reduction
+// order (thread-sequential, xor butterfly inside a wave, waves in order): the result depends on the data only.
+// The two sources of a virtual concat may come with different slab sizes (32-row slabs of the GEMM / conv epilogues,
+// 256-pixel tiles of mimo_conv3x3_fused).
 // ---------------------------------------------------------------------------------
-struct Moments {
-  double n, mean, m2;
-};
-__device__ __forceinline__ Moments merge(const Moments& a, const Moments& b) {
-  if (b.n == 0.0) return a;
-  if (a.n == 0.0) return b;
-  const double n = a.n + b.n, d = b.mean - a.mean;
-  return Moments{n, a.mean + d * (b.n / n), a.m2 + b.m2 + d * d * (a.n * b.n / n)};
-}
-
-__global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, int C1, const float* cs2, int C2,
-                                                            int64_t slabs_per_img, int rows_per_slab, int groups, int total, float eps,
-                                                            float* stats) {
-  const int ig = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (ig >= total) return;
+__global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, int C1, int rows1, const float* cs2, int C2, int rows2,
+                                                            int64_t HW, int groups, float eps, float* stats) {
+  const int ig = blockIdx.x;
   const int img = ig / groups, grp = ig % groups;
-  const int cpg = (C1 + C2) / groups, c0 = grp * cpg;
-  const int64_t items = slabs_per_img * cpg;
-  Moments acc{0.0, 0.0, 0.0};
-  for (int64_t i = lane; i < items; i += 64) {
-    const int64_t sl = img * slabs_per_img + i / cpg;
-    const int c = c0 + (int)(i % cpg);
-    const float* p = c < C1 ? cs1 + sl * 2 * C1 + c : cs2 + sl * 2 * C2 + (c - C1);
-    const int Cx = c < C1 ? C1 : C2;
-    acc = merge(acc, Moments{(double)rows_per_slab, (double)p[0], (double)p[Cx]});
-  }
+  const int cpg = (C1 + C2) / groups, c0 = grp * cpg, c1 = c0 + cpg;
+  __shared__ double red[4];
+  auto block_sum = [&](double v) -> double {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    Moments other{__shfl_xor(acc.n, o, 64), __shfl_xor(acc.mean, o, 64), __shfl_xor(acc.m2, o, 64)};
-    // both partners must compute the same value: merge in a canonical (lower lane first) order
-    acc = (lane & o) ? merge(other, acc) : merge(acc, other);
-  }
-  if (lane == 0) {
-    stats[(int64_t)ig * 2 + 0] = (float)acc.mean;
-    stats[(int64_t)ig * 2 + 1] = rsqrtf((float)(acc.m2 / acc.n) + eps);
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // (red is reused by the second pass)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+  };
+  // columns [lo, hi) of a source with Cx columns and `rows` pixels per slab; f(rows, mean_i, m2_i) summed over the items
+  auto walk = [&](const float* cs, int Cx, int lo, int hi, int rows, auto f) -> double {
+    const int nch = hi - lo;
+    double acc = 0.0;
+    if (nch <= 0) return acc;
+    const int64_t slabs = HW / rows, items = slabs * nch;
+    const float* base = cs + img * slabs * 2 * Cx + lo;
+    for (int64_t i = threadIdx.x; i < items; i += 256) {
+      const float* p = base + (i / nch) * 2 * Cx + (int)(i % nch);
+      acc += f((double)rows, (double)p[0], (double)p[Cx]);
+    }
+    return acc;
+  };
+  const int lo1 = min(c0, C1), hi1 = min(c1, C1), lo2 = max(c0, C1) - C1, hi2 = max(c1, C1) - C1;
+  const double n = (double)HW * (double)cpg;
+  auto wsum = [](double r, double m, double) { return r * m; };
+  const double mean = block_sum(walk(cs1, C1, lo1, hi1, rows1, wsum) + walk(cs2, C2, lo2, hi2, rows2, wsum)) / n;
+  auto dev2 = [mean](double r, double m, double m2) { return m2 + r * (m - mean) * (m - mean); };
+  const double q = block_sum(walk(cs1, C1, lo1, hi1, rows1, dev2) + walk(cs2, C2, lo2, hi2, rows2, dev2));
+  if (threadIdx.x == 0) {
+    stats[(int64_t)ig * 2 + 0] = (float)mean;
+    stats[(int64_t)ig * 2 + 1] = rsqrtf((float)(q / n) + eps);
   }
 }
 
@@ -508,20 +512,20 @@ extern "C" int mimo_group_norm_stats(const void* x1, int C1, const void* x2, int
   return MIMO_OK;
 }
 
-extern "C" int mimo_group_norm_stats_slabs(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW, int rows_per_slab,
-                                           int groups, float eps, float* stats, void* stream) {
-  if (!cs1 || !stats || n <= 0 || HW <= 0 || rows_per_slab <= 0 || (HW % rows_per_slab) || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
-  if ((C1 + C2) % groups || (C2 > 0 && !cs2)) return MIMO_EINVAL;
+extern "C" int mimo_group_norm_stats_slabs(const float* cs1, int C1, int rows_per_slab1, const float* cs2, int C2, int rows_per_slab2,
+                                           int n, int64_t HW, int groups, float eps, float* stats, void* stream) {
+  if (!cs1 || !stats || n <= 0 || HW <= 0 || rows_per_slab1 <= 0 || (HW % rows_per_slab1) || groups <= 0 || C1 <= 0 || C2 < 0) return MIMO_EINVAL;
+  if ((C1 + C2) % groups || (C2 > 0 && (!cs2 || rows_per_slab2 <= 0 || (HW % rows_per_slab2)))) return MIMO_EINVAL;
   const int total = n * groups;
-  hipLaunchKernelGGL(gn_stats_cols_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cs1, C1,
-                     cs2, C2, HW / rows_per_slab, rows_per_slab, groups, total, eps, stats);
+  hipLaunchKernelGGL(gn_stats_cols_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, cs1, C1,
+                     rows_per_slab1, cs2, C2, C2 > 0 ? rows_per_slab2 : rows_per_slab1, HW, groups, eps, stats);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }
 
 extern "C" int mimo_group_norm_stats_cols(const float* cs1, int C1, const float* cs2, int C2, int n, int64_t HW,
                                           int groups, float eps, float* stats, void* stream) {
-  return mimo_group_norm_stats_slabs(cs1, C1, cs2, C2, n, HW, 32, groups, eps, stats, stream);
+  return mimo_group_norm_stats_slabs(cs1, C1, 32, cs2, C2, 32, n, HW, groups, eps, stats, stream);
 }
 
 extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32,

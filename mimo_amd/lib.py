@@ -53,7 +53,7 @@ SIGNATURES = {
     "mimo_conv2d_ext": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz,
                         ctypes.POINTER(EpilogueExt), c_vp],
     "mimo_group_norm_stats_cols": [c_vp, c_i, c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
-    "mimo_group_norm_stats_slabs": [c_vp, c_i, c_vp, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp, c_vp],
+    "mimo_group_norm_stats_slabs": [c_vp, c_i, c_i, c_vp, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
     "mimo_group_norm_affine": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
@@ -65,9 +65,10 @@ SIGNATURES = {
     "mimo_attention_fp8qk": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp],
     "mimo_ff_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
-    "mimo_ff_proj_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
+    "mimo_ff_proj_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp,
+                           c_vp],
     "mimo_block_tail_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
-                              c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
+                              c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
     "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
     "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],

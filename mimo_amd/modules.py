@@ -198,7 +198,8 @@ class ResnetBlock(HipModule):
         if not fused_sc and ops.hconv_supported(h, cout):
             st2 = ops.group_norm_stats(h, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
             ab2 = ops.group_norm_affine(st2, p["g2"], p["be2"], cout, self.groups)
-            return ops.conv3x3_fused(h, p["w2"], cout, ab=ab2, bias=p["b2"], residual=x, out_scale=1.0 / self.output_scale_factor)
+            return ops.conv3x3_fused(h, p["w2"], cout, ab=ab2, bias=p["b2"], residual=x, out_scale=1.0 / self.output_scale_factor,
+                                     tile_stats=True)
         if band:
             st2 = ops.group_norm_stats(h, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
             out = torch.empty_like(h)
@@ -258,7 +259,7 @@ class Upsample(HipModule):
         n, H, W, _ = x.shape
         if output_size is None and ops.hconv_supported(x, self.conv.out_channels, normed=False, upsample2x=True):
             # the convolution gathers the nearest-x2 image from the fp32 source itself: no cast pass, no half intermediate
-            return ops.conv3x3_fused(x, p["w"], self.conv.out_channels, bias=p["b"], upsample2x=True)
+            return ops.conv3x3_fused(x, p["w"], self.conv.out_channels, bias=p["b"], upsample2x=True, tile_stats=True)
         if output_size is None and banded(ctx, 2 * H, 2 * W):
             # row bands of the UPSAMPLED image (even boundaries): output rows [y0, y1) read virtual rows y0 - 1 .. y1, i.e.
             # source rows y0 / 2 - 1 .. y1 / 2; the band's virtual image starts at source row lo, so the first virtual row
@@ -326,12 +327,13 @@ def _ff_proj_run(ctx, p, y_f32, n3, proj, x_f32, colstats):
     """Feed-forward + the block's output projection + its residual: x + proj_out(y + FF(n3)).  proj = dict(po_w, po_b,
     po_wk) of the owning module.  One launch where the fused kernel applies (C = 320), three otherwise."""
     if ops.FF_PROJ_FUSED and proj.get("po_wk") is not None and _ff_fusable(p, n3, False):
-        return ops.ff_proj_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], y_f32, proj["po_wk"], proj["po_b"], x_f32)
+        return ops.ff_proj_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], y_f32, proj["po_wk"], proj["po_b"], x_f32,
+                                 colstats=colstats)
     z = _ff_run(ctx, p, y_f32, n3, out_f32=False)
     return ops.gemm(z, proj["po_w"], bias=proj["po_b"], residual=x_f32, out_f32=True, colstats=colstats)
 
 
-def _block_tail_run(ctx, p, o, t, proj, x_f32, keys, ln_eps, img_bias=None, rows_per_img=1):
+def _block_tail_run(ctx, p, o, t, proj, x_f32, keys, ln_eps, img_bias=None, rows_per_img=1, colstats=False):
     """Everything after a block's attention core + the owning transformer's proj_out in one launch (C = 320), or None when
     the fused kernel does not apply.  keys = (to_out bias, LN gamma, LN beta) names in p; proj["tail_ws"] = the weight stream."""
     ws = proj.get("tail_ws")
@@ -342,7 +344,7 @@ def _block_tail_run(ctx, p, o, t, proj, x_f32, keys, ln_eps, img_bias=None, rows
     if img_bias is not None and (img_bias.data_ptr() % 16 or img_bias.stride(0) % 4 or rows_per_img < 128):
         return None
     return ops.block_tail_fused(o, ws, p[keys[0]], t, p[keys[1]], p[keys[2]], ln_eps, p["ff1_b"], p["ff2_wk"], p["ff2_b"],
-                                proj["po_b"], x_f32, img_bias=img_bias, rows_per_img=rows_per_img)
+                                proj["po_b"], x_f32, img_bias=img_bias, rows_per_img=rows_per_img, colstats=colstats)
 
 
 class SpatialTransformerBlock(HipModule):
@@ -416,7 +418,7 @@ class SpatialTransformerBlock(HipModule):
         s, e = self.attn2_slice
         if proj is not None:
             out = _block_tail_run(ctx, p, o.view(-1, C), t, proj, x, ("o_b", "n3w", "n3b"), self.norm3.eps,
-                                  img_bias=ctx.attn2[:, s:e], rows_per_img=ctx.F * N)
+                                  img_bias=ctx.attn2[:, s:e], rows_per_img=ctx.F * N, colstats=N)
             if out is not None:
                 return out
         # to_out + collapsed attn2 + residual, with norm3 of the result fused into the same epilogue (C = 320)
@@ -563,7 +565,7 @@ class MotionModule(HipModule):
             qkv = ops.gemm(u, p[f"qkv{i}"])
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
             if i == 1:  # ... + to_out + residual + LayerNorm + feed-forward + proj_out + residual: one launch at C = 320
-                out = _block_tail_run(ctx, p, o, t, p, x.view(-1, C), ("o_b1", "fnw", "fnb"), blk_eps)
+                out = _block_tail_run(ctx, p, o, t, p, x.view(-1, C), ("o_b1", "fnw", "fnb"), blk_eps, colstats=HW)
                 if out is not None:
                     break
             t, u = ops.gemm(o, p[f"o_w{i}"], bias=p[f"o_b{i}"], residual=t, out_f32=True, ln=ln[i + 1])

@@ -270,9 +270,22 @@ def ff_fused(a, w1p, b1p, w2k, b2, residual):
     return out
 
 
-def ff_proj_fused(a, w1p, b1p, w2k, b2, residual, wpk, bp, x):
+FF_COLSTATS = True  # the fused tails also emit the GroupNorm column statistics of their output (no statistics pass after them)
+
+
+def _tail_colstats(colstats, M, C, device):
+    """[M/32, 2, C] statistics buffer of a fused tail, or None.  colstats = rows per image; like _want_colstats a function
+    of the image size only (whole 32-row slabs per image), never of the batch."""
+    hw = int(colstats or 0)
+    if FF_COLSTATS and hw >= 32 and hw % 32 == 0 and M % hw == 0:
+        return torch.empty((M // 32, 2, C), device=device, dtype=torch.float32)
+    return None
+
+
+def ff_proj_fused(a, w1p, b1p, w2k, b2, residual, wpk, bp, x, colstats=False):
     """fp32 [M, C] = x + (residual + FF(a)) @ Wp^T + bp in ONE launch (C = 320): ff_fused with the block's output projection
-    and its residual folded in; wpk = packing.pack_proj_tail(proj_out.weight)."""
+    and its residual folded in; wpk = packing.pack_proj_tail(proj_out.weight).  colstats=<rows per image>: the launch also
+    emits the GroupNorm column statistics of its output (attached as out._cs)."""
     _chk(a, "a")
     M, C = a.shape
     assert a.stride(1) == 1 and w1p.shape == (8 * C, C) and w2k.shape == (C, 4 * C) and wpk.shape == (C, C)
@@ -280,16 +293,18 @@ def ff_proj_fused(a, w1p, b1p, w2k, b2, residual, wpk, bp, x):
     for r in (residual, x):
         assert r.dtype == torch.float32 and r.shape == (M, C) and r.stride(1) == 1
     out = torch.empty((M, C), device=a.device, dtype=torch.float32)
+    cs = _tail_colstats(colstats, M, C, a.device)
     fl = 2 * M * C * (8 * C + 4 * C + C)
     _count(fl)
-    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, wpk, residual, x, out), f"ff_proj_fused M{M}"):
+    with _Bracket("gemm_kernel", fl, _nbytes(a, w1p, w2k, wpk, residual, x, out, cs), f"ff_proj_fused M{M}"):
         L.call("mimo_ff_proj_fused", dt_code(a.dtype), a.data_ptr(), a.stride(0), w1p.data_ptr(), _ptr(b1p), w2k.data_ptr(),
                _ptr(b2), residual.data_ptr(), residual.stride(0), wpk.data_ptr(), _ptr(bp), x.data_ptr(), x.stride(0),
-               out.data_ptr(), out.stride(0), M, C, _stream())
-    return out
+               out.data_ptr(), out.stride(0), M, C, _ptr(cs), _stream())
+    return with_stats(out, cs)
 
 
-def block_tail_fused(o, wstream, bo, residual, ln_gamma, ln_beta, ln_eps, b1p, w2k, b2, bp, x, img_bias=None, rows_per_img=1):
+def block_tail_fused(o, wstream, bo, residual, ln_gamma, ln_beta, ln_eps, b1p, w2k, b2, bp, x, img_bias=None, rows_per_img=1,
+                     colstats=False):
     """fp32 [M, C] = x + (y + FF(LayerNorm(y))) @ Wp^T + bp with y = residual + o @ Wo^T + bo (+ img_bias per image) in ONE
     launch (C = 320): everything a transformer block does after its attention core plus the owning transformer's proj_out;
     wstream = packing.pack_block_tail_stream(to_out.weight, GEGLU-packed FF1, proj_out.weight)."""
@@ -304,14 +319,15 @@ def block_tail_fused(o, wstream, bo, residual, ln_gamma, ln_beta, ln_eps, b1p, w
         assert img_bias.shape[0] * rows_per_img >= M
         ldib = img_bias.stride(0)
     out = torch.empty((M, C), device=o.device, dtype=torch.float32)
+    cs = _tail_colstats(colstats, M, C, o.device)  # colstats=<rows per image>: GroupNorm column statistics of out as out._cs
     fl = 2 * M * C * (C + 8 * C + 4 * C + C)
     _count(fl)
-    with _Bracket("gemm_kernel", fl, _nbytes(o, wstream, w2k, residual, x, out), f"block_tail_fused M{M}"):
+    with _Bracket("gemm_kernel", fl, _nbytes(o, wstream, w2k, residual, x, out, cs), f"block_tail_fused M{M}"):
         L.call("mimo_block_tail_fused", dt_code(o.dtype), o.data_ptr(), o.stride(0), wstream.data_ptr(), _ptr(bo), _ptr(img_bias),
                ldib, rows_per_img, residual.data_ptr(), residual.stride(0), ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps),
                _ptr(b1p), w2k.data_ptr(), _ptr(b2), _ptr(bp), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, C,
-               _stream())
-    return out
+               _ptr(cs), _stream())
+    return with_stats(out, cs)
 
 
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
@@ -391,12 +407,15 @@ def group_norm_stats(x1, *, groups=32, eps=1e-5, x2=None, dtype=None):
         assert _is_f32(x2) == f32 and x2.numel() // (n * C2) == HW
     cs1, cs2 = stats_of(x1), (None if x2 is None else stats_of(x2))
     stats = torch.empty((n, groups, 2), device=x1.device, dtype=torch.float32)
-    if cs1 is not None and (x2 is None or cs2 is not None) and (n * HW) % cs1.shape[0] == 0 \
-            and HW % ((n * HW) // cs1.shape[0]) == 0 and (cs2 is None or cs2.shape[0] == cs1.shape[0]):
-        # the producers' epilogues already reduced every slab (32 rows: mimo_gemm_ext / mimo_conv2d_ext column statistics;
-        # 256 pixels: mimo_conv3x3_fused tile statistics): merge slabs x group columns, no pass over x
-        L.call("mimo_group_norm_stats_slabs", cs1.data_ptr(), C1, _ptr(cs2), C2, n, HW, (n * HW) // cs1.shape[0], groups,
-               float(eps), stats.data_ptr(), _stream())
+    def slab_rows(cs):  # pixels per partial of a producer's statistics, or 0 when they do not tile an image
+        rows = (n * HW) // cs.shape[0] if (n * HW) % cs.shape[0] == 0 else 0
+        return rows if rows and HW % rows == 0 else 0
+    if cs1 is not None and (x2 is None or cs2 is not None) and slab_rows(cs1) and (cs2 is None or slab_rows(cs2)):
+        # the producers' epilogues already reduced every slab (32 rows: mimo_gemm_ext / mimo_conv2d_ext / the fused tails /
+        # mimo_conv3x3_fused with a residual; 256 pixels: mimo_conv3x3_fused tile statistics): merge slabs x group
+        # columns, no pass over x
+        L.call("mimo_group_norm_stats_slabs", cs1.data_ptr(), C1, slab_rows(cs1), _ptr(cs2), C2, slab_rows(cs2) if cs2 is not None else 0,
+               n, HW, groups, float(eps), stats.data_ptr(), _stream())
         return stats
     C = C1 + C2
     if C1 % 4 == 0 and C2 % 4 == 0 and groups <= C // 4 <= 1024 and HW * C >= (1 << 20):
@@ -466,7 +485,8 @@ def group_norm_affine(stats, gamma, beta, C, groups=32):
 # quantise worse than the row-tiled kernel's 192-row tiles (32 x 32 x 48 images x 640 channels = 384 blocks on 256 CUs).
 HCONV = True
 HCONV_MIN_HW = 4096
-HCONV_TILE_STATS = True   # conv3x3_fused(tile_stats=True) also emits per-tile GroupNorm statistics of its output
+HCONV_TILE_STATS = True
+HCONV_SLAB_STATS = True  # ... also with a residual (32-pixel slabs) and for the up-sampling convolution   # conv3x3_fused(tile_stats=True) also emits per-tile GroupNorm statistics of its output
 
 
 def hconv_supported(x1, cout, *, x2=None, normed=True, upsample2x=False):
@@ -492,7 +512,7 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
     """fp32 [n, H, W, cout] = epilogue(conv3x3(silu(x * a + b))) in ONE launch: x = fp32 virtual concat [x1 | x2], ab from
     group_norm_affine (None: plain cast, no SiLU — the up-sampling convolution); w = the packed weight of conv2d
     (columns beyond 9 C, a fused shortcut segment, are ignored).  want_raw: also returns the half cast of x.
-    tile_stats: also emit the per-(16 x 16 tile, channel) statistics of `out` (attached as out._cs): the GroupNorm that
+    tile_stats: also emit per-(16 x 16 tile | with a residual: 32-pixel slab, channel) statistics of `out` (attached as out._cs): the GroupNorm that
     consumes `out` then merges them instead of making a statistics pass over the tensor."""
     _chk(x1, "x1")
     assert x1.dim() == 4 and x1.is_contiguous() and x1.dtype == torch.float32 and w.is_contiguous()
@@ -520,8 +540,13 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
         assert img_bias.dim() == 2 and img_bias.stride(1) == 1 and img_bias.dtype == torch.float32
         ldib = img_bias.stride(0)
     p = L.HconvParams(n, H, W, cout, int(upsample2x), imgs_per_bias_row, ldib)
-    ts = torch.empty((n * (H // 16) * (W // 16), 2, cout), device=x1.device, dtype=torch.float32) \
-        if (tile_stats and HCONV_TILE_STATS and residual is None and ab is not None) else None
+    ts = None
+    if tile_stats and HCONV_TILE_STATS:
+        if residual is None and (ab is not None or HCONV_SLAB_STATS):      # per 16 x 16 tile, from the accumulators
+            ts = torch.empty((n * (H // 16) * (W // 16), 2, cout), device=x1.device, dtype=torch.float32)
+        elif residual is not None and HCONV_SLAB_STATS and ab is not None and not want_raw:
+            # per 32-pixel slab (two tile rows), from the stored values (residual included)
+            ts = torch.empty((n * H * W // 32, 2, cout), device=x1.device, dtype=torch.float32)
     fl = 2 * n * H * W * cout * 9 * C
     _count(fl)
     with _Bracket("gemm_kernel", fl, _nbytes(x1, x2, out, residual, raw) + cout * 9 * C * w.element_size(),

@@ -293,6 +293,37 @@ def test_conv3x3_fused_groupnorm_silu(dev, dtype, case):
         ref_var = o_pl.view(n, H * W, 32, cout // 32).double().var(dim=(1, 3), unbiased=False)
         assert float((st_merge[..., 0].double() - ref_mean).abs().max()) < 1e-5 * (1 + float(ref_mean.abs().max()))
         assert rel_l2(st_merge[..., 1], (ref_var + 1e-5).rsqrt()) < 1e-5 and rel_l2(st_pass[..., 1], st_merge[..., 1]) < 1e-5
+    if cout % 32 == 0 and (gn or ups):
+        def check_stats(t, plain, rows):
+            cs = ops.stats_of(t)
+            assert cs is not None and cs.shape == (n * H * W // rows, 2, cout) and torch.equal(t, plain)
+            st = ops.group_norm_stats(t, groups=32, eps=1e-5, dtype=dtype)
+            v = plain.view(n, H * W, 32, cout // 32).double()
+            ref_mean, ref_var = v.mean(dim=(1, 3)), v.var(dim=(1, 3), unbiased=False)
+            assert float((st[..., 0].double() - ref_mean).abs().max()) < 1e-5 * (1 + float(ref_mean.abs().max()))
+            assert rel_l2(st[..., 1], (ref_var + 1e-5).rsqrt()) < 1e-5
+            return cs
+        if gn:
+            # with a residual (the ResBlock's second convolution): statistics of the STORED values per 32-pixel slab
+            kw = dict(x2=x2, ab=ab, bias=b, residual=res, out_scale=0.5)
+            cs_a = check_stats(ops.conv3x3_fused(x1, wp, cout, tile_stats=True, **kw), ops.conv3x3_fused(x1, wp, cout, **kw), 32)
+        else:
+            # the up-sampling convolution (no affine): tile statistics from the accumulators
+            kw = dict(bias=b, upsample2x=True)
+            cs_a = check_stats(ops.conv3x3_fused(x1, wp, cout, tile_stats=True, **kw), ops.conv3x3_fused(x1, wp, cout, **kw), 256)
+        # a virtual concat whose two sources carry statistics of DIFFERENT slab sizes merges without a pass over either
+        ta = ops.conv3x3_fused(x1, wp, cout, tile_stats=True, **kw)
+        tb = rnd((n, H, W, 64), dev, torch.float32, 21, 1.5) - 0.2
+        v = tb.view(n, H * W // 32, 32, 64).double()
+        cs_b = torch.stack([v.mean(dim=2), ((v - v.mean(dim=2, keepdim=True)) ** 2).sum(dim=2)], dim=2).float().reshape(-1, 2, 64).contiguous()
+        if (cout + 64) % 32 == 0:
+            for first, second in ((ta, ops.with_stats(tb, cs_b)), (ops.with_stats(tb, cs_b), ta)):
+                st = ops.group_norm_stats(first, groups=32, eps=1e-5, x2=second, dtype=dtype)
+                cat = torch.cat([first, second], dim=-1)
+                Cc = cat.shape[-1]
+                vv = cat.view(n, H * W, 32, Cc // 32).double()
+                assert float((st[..., 0].double() - vv.mean(dim=(1, 3))).abs().max()) < 2e-5
+                assert rel_l2(st[..., 1], (vv.var(dim=(1, 3), unbiased=False) + 1e-5).rsqrt()) < 1e-5
     one = ops.conv3x3_fused(x1[-1:].contiguous(), pack_conv(w, dtype), cout, x2=None if x2 is None else x2[-1:].contiguous(),
                             ab=None if ab is None else ab[-1:].contiguous(), upsample2x=ups)
     assert torch.equal(one, out[-1:])
@@ -543,8 +574,25 @@ def test_ff_fused_c320(dev, dtype, M):
     assert rel_l2(out[M // 2].float(), ref[M // 2]) < 2 * OUT_TOL[dtype] and rel_l2(out[:, 7].float(), ref[:, 7]) < 2 * OUT_TOL[dtype]
 
 
+def _check_tail_colstats(ops, run, plain, M, hw, dtype):
+    """A fused tail called with colstats=<rows per image> writes the same output bits and attaches per-32-row-slab column
+    statistics that merge to the GroupNorm statistics a pass over the output computes."""
+    out = run(colstats=hw)
+    cs = ops.stats_of(out)
+    C = plain.shape[1]
+    assert cs is not None and cs.shape == (M // 32, 2, C) and torch.equal(out, plain)
+    v = plain.view(M // 32, 32, C).double()
+    assert float((cs[:, 0].double() - v.mean(dim=1)).abs().max()) < 1e-5 * (1 + float(plain.abs().max()))
+    assert rel_l2(cs[:, 1], ((v - v.mean(dim=1, keepdim=True)) ** 2).sum(dim=1)) < 1e-5
+    img = ops.with_stats(out.view(M // hw, hw, 1, C), cs)
+    st = ops.group_norm_stats(img, groups=32, eps=1e-6, dtype=dtype)
+    vv = plain.view(M // hw, hw, 32, C // 32).double()
+    assert float((st[..., 0].double() - vv.mean(dim=(1, 3))).abs().max()) < 1e-5 * (1 + float(plain.abs().max()))
+    assert rel_l2(st[..., 1], (vv.var(dim=(1, 3), unbiased=False) + 1e-6).rsqrt()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [128, 8192 + 77, 33, 40000])
+@pytest.mark.parametrize("M", [128, 8192 + 77, 33, 40000, 4096])
 def test_ff_proj_fused_c320(dev, dtype, M):
     """mimo_ff_proj_fused (C = 320): x + (residual + FF(a)) Wp^T + bp in one launch vs the three launches it replaces and a
     torch fp32 reference with the kernel's two half roundings (hidden activations, FF result)."""
@@ -572,6 +620,9 @@ def test_ff_proj_fused_c320(dev, dtype, M):
     three = ops.gemm(zz, wp.to(dtype).contiguous(), bias=bp, residual=x, out_f32=True)
     assert rel_l2(out, three) < OUT_TOL[dtype]
     assert rel_l2(out[M // 2], ref[M // 2]) < 1e-4 and rel_l2(out[:, 161], ref[:, 161]) < 1e-4 and rel_l2(out[:, 7], ref[:, 7]) < 1e-4
+    if M % 128 == 0:
+        _check_tail_colstats(ops, lambda **kw: ops.ff_proj_fused(a, w1p, b1p, pack_ff2_kperm(w2, dtype), b2, res, pack_proj_tail(wp, dtype), bp, x, **kw),
+                             out, M, 64, dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -622,6 +673,10 @@ def test_block_tail_fused_c320(dev, dtype, M, rows_per_img):
     assert rel_l2(out, four) < OUT_TOL[dtype]
     assert rel_l2(out[M // 2], ref[M // 2]) < OUT_TOL[dtype] and rel_l2(out[:, 161], ref[:, 161]) < OUT_TOL[dtype]
     assert rel_l2(out[:, 7], ref[:, 7]) < OUT_TOL[dtype] and rel_l2(out[-1], ref[-1]) < OUT_TOL[dtype]
+    if M % 128 == 0:
+        _check_tail_colstats(ops, lambda **kw: ops.block_tail_fused(o, ws, bo, t, gamma, beta, 1e-5, b1p, pack_ff2_kperm(w2, dtype), b2, bp, x,
+                                                                    img_bias=ib, rows_per_img=rows_per_img or 1, **kw),
+                             out, M, 128 if rows_per_img else 64, dtype)
 
 
 def test_block_tail_fused_is_batch_invariant(dev):
