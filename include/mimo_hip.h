@@ -148,6 +148,14 @@ int mimo_conv2d(int dtype, const void* in, const void* in2, const void* W, void*
                 const mimo_conv_params* p, const float* bias, const float* img_bias,
                 const void* residual, float out_scale, unsigned flags, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* Thin-output 3x3 convolution (Cout <= 16: UNet conv_out, src/models/unet_3d_edit_bkfill.py:560-563; VAE decoder conv_out,
+ * diffusers AutoencoderKL.decode via pipeline_..._roiclip.py:120) as GEMM + gather: taps = mimo_gemm(in[M, Cin],
+ * Wt[9 Cout, Cin]) (Wt row tap * Cout + c = weight[c, :, ky, kx]: mimo_amd.packing.pack_conv_taps; fp32 out) holds every
+ * pixel's contribution to the nine outputs around it, the input is read once; this call sums them:
+ *   out[n, y, x, c] (fp32) = (bias[c] + sum_{ky,kx} taps[(n, y + ky - 1, x + kx - 1)][(3 ky + kx) Cout + c]) * out_scale
+ * (padding = 1, stride 1, fixed tap order).  taps: fp32 [n*H*W, ldt], ldt >= 9 Cout; Cout in {4, 8, 16}. */
+int mimo_conv3x3_tapsum(const float* taps, int64_t ldt, int n, int H, int W, int cout, const float* bias, float* out,
+                        float out_scale, void* stream);
 /* as mimo_conv2d, plus ext->colstats (ext->ln_out must be NULL) */
 int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const void* W, void* out,
                     const mimo_conv_params* p, const float* bias, const float* img_bias,

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 LIB_PATH = os.path.join(ROOT, "libmimo_hip.so")
-SOURCES = ["gemm_conv.hip", "hconv.hip", "gemm_stream.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip", "image.hip"]
+SOURCES = ["gemm_conv.hip", "hconv.hip", "thinconv.hip", "gemm_stream.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 

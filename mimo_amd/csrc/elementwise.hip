@@ -108,6 +108,50 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* acc, const f
   }
 }
 
+// Second half of a thin-output 3x3 convolution (Cout <= 16: conv_out of the UNet and of the VAE decoder).  The first half is a
+// plain GEMM of the input pixels with the weight regrouped as [9 taps x Cout][Cin] (mimo_amd.packing.pack_conv_taps): every
+// pixel's contribution to each of the nine output positions it touches, taps[m][tap * Cout + c], the input read ONCE.  This
+// kernel gathers them: out[y][x][c] = bias[c] + sum_tap taps[(y + ky - 1, x + kx - 1)][tap][c] (fixed tap order, zero outside
+// the image).  A block owns TH x 32 output pixels (TH = 8 / (Cout / 4)): the (TH + 2) x 34 tap rows they need come in as whole
+// contiguous rows (lane = consecutive 16-byte piece: full cache lines; a per-pixel gather would pull a 128-byte line for every
+// 16 bytes it uses) into LDS, then one thread per (pixel, 4 channels) sums its nine pieces.
+template <int C4>
+__global__ __launch_bounds__(256) void conv3x3_tapsum_kernel(const float* taps, int64_t ldt, int n, int H, int W,
+                                                             const float* bias, float* out, float out_scale) {
+  constexpr int TH = 8 / C4, TW = 32, COUT = 4 * C4;
+  constexpr int PCS = 9 * C4;                     // 16-byte pieces per tap row
+  constexpr int NPIX = (TH + 2) * (TW + 2);
+  __shared__ float4 tile[NPIX * PCS];
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int bx = blockIdx.x % tiles_x;
+  const int by = (blockIdx.x / tiles_x) % tiles_y;
+  const int64_t img = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = by * TH, x0 = bx * TW;
+  for (int i = threadIdx.x; i < NPIX * PCS; i += 256) {
+    const int pix = i / PCS, pc = i - pix * PCS;
+    const int r = pix / (TW + 2), c = pix - r * (TW + 2);
+    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+      v = *reinterpret_cast<const float4*>(taps + ((img * H + yy) * W + xx) * ldt + 4 * pc);
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int cq = threadIdx.x % C4, tx = (threadIdx.x / C4) % TW, ty = threadIdx.x / (C4 * TW);
+  const int y = y0 + ty, x = x0 + tx;
+  if (y >= H || x >= W) return;
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float4 v = tile[((ty + ky) * (TW + 2) + tx + kx) * PCS + (ky * 3 + kx) * C4 + cq];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  acc.x *= out_scale; acc.y *= out_scale; acc.z *= out_scale; acc.w *= out_scale;
+  *reinterpret_cast<float4*>(out + ((img * H + y) * W + x) * COUT + 4 * cq) = acc;
+}
+
 }  // namespace
 
 extern "C" int mimo_ncfhw_to_tokens(const void* in, int in_is_f32, int dtype, int b, int C, int F, int H,
@@ -176,6 +220,26 @@ extern "C" int mimo_cfg_ddim_step(const float* acc, const float* counter, float*
   if (!acc || !counter || !latents || C <= 0 || F <= 0 || HW <= 0) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_grid((int64_t)C * F * HW)), dim3(256), 0, st, acc, counter, latents, C, F, HW, cfg, guidance, sqrt_a_t, sqrt_1ma_t, sqrt_a_prev, sqrt_1ma_prev);
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_conv3x3_tapsum(const float* taps, int64_t ldt, int n, int H, int W, int cout, const float* bias, float* out,
+                                   float out_scale, void* stream) {
+  if (!taps || !out || n <= 0 || H <= 0 || W <= 0 || cout <= 0 || (cout & 3) || cout > 16 || ldt < 9 * (int64_t)cout || (ldt & 3))
+    return MIMO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(taps) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)))
+    return MIMO_EINVAL;
+  const int c4 = cout >> 2;
+  if (c4 != 1 && c4 != 2 && c4 != 4) return MIMO_EINVAL;
+  const int th = 8 / c4;
+  const int64_t blocks = (int64_t)n * ((H + th - 1) / th) * ((W + 31) / 32);
+  if (blocks > 0x7fffffff) return MIMO_EINVAL;
+  const dim3 gr((unsigned)blocks), bl(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (c4 == 1) hipLaunchKernelGGL(conv3x3_tapsum_kernel<1>, gr, bl, 0, st, taps, ldt, n, H, W, bias, out, out_scale);
+  else if (c4 == 2) hipLaunchKernelGGL(conv3x3_tapsum_kernel<2>, gr, bl, 0, st, taps, ldt, n, H, W, bias, out, out_scale);
+  else hipLaunchKernelGGL(conv3x3_tapsum_kernel<4>, gr, bl, 0, st, taps, ldt, n, H, W, bias, out, out_scale);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }

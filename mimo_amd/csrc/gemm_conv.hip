@@ -24,6 +24,7 @@
 
 #include "common.cuh"
 #include "gemm_stream.cuh"
+#include "thinconv.cuh"
 
 namespace {
 
@@ -1584,6 +1585,21 @@ extern "C" int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const
   if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32 | MIMO_EPI_NO_SPLITK)) return MIMO_EINVAL;
   if (!aligned16(in) || !aligned16(W) || !aligned16(out) || (in2 && !aligned16(in2))) return MIMO_EINVAL;
   if (ext && ext->ln_out) return MIMO_EINVAL;  // the fused LayerNorm output exists for dense GEMMs only
+  // thin-input layers (pose guider, VAE conv_in): direct convolution, see thinconv.hip
+  if (tune_env("MIMO_THIN_CONV", 1) && !in2 && p->Cin2 == 0 && !img_bias && !residual && !(ext && ext->colstats) && p->Hup == 0 &&
+      !(flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_NO_SPLITK))) {
+    const int64_t ib = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2;
+    const int64_t ob = (int64_t)p->n * p->Hout * p->Wout * p->Cout * ((flags & MIMO_EPI_OUT_F32) ? 4 : 2);
+    if (mimo_thin::supported(p->Cin, p->Cout, p->ksize, p->stride, ib, ob) && (p->ksize == 3 || (p->pad_t == 0 && p->pad_l == 0))) {
+      mimo_thin::Args a{};
+      a.in = (const uint16_t*)in; a.W = (const uint16_t*)W; a.out = out; a.bias = bias;
+      a.n = p->n; a.Hin = p->Hin; a.Win = p->Win; a.Cin = p->Cin; a.Hout = p->Hout; a.Wout = p->Wout; a.Cout = p->Cout;
+      a.ksize = p->ksize; a.stride = p->stride; a.pad_t = p->pad_t; a.pad_l = p->pad_l; a.ldw = (int64_t)p->ksize * p->ksize * p->Cin;
+      a.out_scale = out_scale; a.flags = flags & (MIMO_EPI_SILU | MIMO_EPI_OUT_F32);
+      a.in_bytes = (unsigned)ib; a.w_bytes = (unsigned)((int64_t)p->Cout * a.ldw * 2); a.out_bytes = (unsigned)ob;
+      return mimo_thin::launch(dtype, a, cus_(), (hipStream_t)stream);
+    }
+  }
   GemmArgs g{};
   g.A = (const uint16_t*)in; g.A2 = (const uint16_t*)in2; g.W = (const uint16_t*)W; g.out = out;
   g.bias = bias; g.img_bias = img_bias; g.res = residual;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mimo_conv2d": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz, c_vp],
     "mimo_conv2d_ext": [c_i, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvParams), c_vp, c_vp, c_vp, c_f, c_u, c_vp, c_sz,
                         ctypes.POINTER(EpilogueExt), c_vp],
+    "mimo_conv3x3_tapsum": [c_vp, c_i64, c_i, c_i, c_i, c_i, c_vp, c_vp, c_f, c_vp],
     "mimo_group_norm_stats_cols": [c_vp, c_i, c_vp, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats_slabs": [c_vp, c_i, c_i, c_vp, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],

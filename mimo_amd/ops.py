@@ -559,6 +559,23 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
     return (out, raw) if want_raw else out
 
 
+THIN_OUT = True  # thin-output 3x3 convolutions (conv_out of the UNet / VAE decoder) as GEMM + tap gather
+
+
+def conv3x3_thin_out(x, w_taps, cout, *, bias=None, out_scale=1.0):
+    """fp32 [n, H, W, cout] = conv3x3(x) (padding 1) for a thin output (cout <= 16): x half [n, H, W, Cin] is read ONCE by a
+    GEMM with w_taps = packing.pack_conv_taps(weight) ([9 cout, Cin]); mimo_conv3x3_tapsum gathers the nine contributions of
+    every output pixel (the implicit-GEMM kernel would spend a 160-column tile on 4 channels and re-read x per tap)."""
+    _chk(x, "x")
+    assert x.dim() == 4 and x.is_contiguous() and w_taps.shape == (9 * cout, x.shape[3]) and cout % 4 == 0 and cout <= 16
+    n, H, W, C = x.shape
+    # (as a 1x1 convolution: mimo_conv2d routes K = 128 | 320 with a thin N to the direct kernel of csrc/thinconv.hip)
+    taps = conv2d(x, w_taps, 9 * cout, ksize=1, out_f32=True)
+    out = torch.empty((n, H, W, cout), device=x.device, dtype=torch.float32)
+    L.call("mimo_conv3x3_tapsum", taps.data_ptr(), 9 * cout, n, H, W, cout, _ptr(bias), out.data_ptr(), float(out_scale), _stream())
+    return out
+
+
 def layer_norm(x, gamma, beta, *, eps=1e-5, dtype=None, pe=None, rows_per_frame=0, pe_frames=0, out_f32=False):
     """LayerNorm over the last dim of x [rows, C] -> half (fp32 if out_f32); optional + pe[(row // rows_per_frame) % pe_frames]."""
     _chk(x, "x")

@@ -20,6 +20,17 @@ def pack_conv(weight, dtype, shortcut=None, cin_pad=None, cout_pad=None):
     return w.to(dtype).contiguous()
 
 
+def pack_conv_taps(weight, dtype, cout_pad=None):
+    """nn.Conv2d 3x3 weight [Cout, Cin, 3, 3] -> [9 * Cout(+pad), Cin], row (3 ky + kx) * Cout + c: the weight of the GEMM half
+    of a thin-output convolution (ops.conv3x3_thin_out: every pixel's contribution to the nine outputs around it)."""
+    co, ci, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().float()
+    if cout_pad is not None and cout_pad > co:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
+    return w.permute(2, 3, 0, 1).reshape(9 * w.shape[0], ci).to(dtype).contiguous()
+
+
 def pad_vec(v, n):
     v = v.detach().float()
     if v.numel() < n:

@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import ops
 from .modules import (Ctx, Downsample, EarlyExit, HipModule, MotionModule, ResnetBlock, SpatialTransformer,
                       SpatialTransformerBlock, Upsample, _f32)
-from .packing import pack_conv, pad_vec
+from .packing import pack_conv, pack_conv_taps, pad_vec
 
 
 class _Linear2(nn.Module):  # diffusers TimestepEmbedding key layout
@@ -188,7 +188,8 @@ class UNetBase(HipModule):
         if self.with_out:
             cout_pad = (self.out_channels + 3) // 4 * 4
             d.update(no_g=_f32(self.conv_norm_out.weight), no_b=_f32(self.conv_norm_out.bias),
-                     co_w=pack_conv(self.conv_out.weight, dt, cout_pad=cout_pad), co_b=pad_vec(self.conv_out.bias, cout_pad))
+                     co_w=pack_conv(self.conv_out.weight, dt, cout_pad=cout_pad), co_b=pad_vec(self.conv_out.bias, cout_pad),
+                     co_wt=pack_conv_taps(self.conv_out.weight, dt, cout_pad=cout_pad))
         half = self.boc[0] // 2
         import math
         d["freqs"] = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=dev) / half)
@@ -273,6 +274,8 @@ class UNetBase(HipModule):
         if not self.with_out:
             return x
         a, _ = ops.group_norm(x, p["no_g"], p["no_b"], groups=self.groups, eps=self.eps, silu=True, dtype=dt)
+        if ops.THIN_OUT and p["co_w"].shape[0] <= 16:
+            return ops.conv3x3_thin_out(a, p["co_wt"], p["co_w"].shape[0], bias=p["co_b"])
         return ops.conv2d(a, p["co_w"], p["co_w"].shape[0], bias=p["co_b"], out_f32=True)
 
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32, banded, gn_conv3x3_banded
-from .packing import pack_conv, pad_vec
+from .packing import pack_conv, pack_conv_taps, pad_vec
 
 
 FLASH_HEAD_DIMS = (64, 80, 160, 512)  # single-head widths mimo_attention has a kernel for
@@ -151,7 +151,8 @@ class Decoder(HipModule):
     def _pack(self, dt):
         return dict(ci_w=pack_conv(self.conv_in.weight, dt, cin_pad=8), ci_b=_f32(self.conv_in.bias),
                     g=_f32(self.conv_norm_out.weight), b=_f32(self.conv_norm_out.bias),
-                    co_w=pack_conv(self.conv_out.weight, dt, cout_pad=4), co_b=pad_vec(self.conv_out.bias, 4))
+                    co_w=pack_conv(self.conv_out.weight, dt, cout_pad=4), co_b=pad_vec(self.conv_out.bias, 4),
+                    co_wt=pack_conv_taps(self.conv_out.weight, dt, cout_pad=4))
 
     def run(self, ctx, z_tok):
         p = self.packed(ctx.dtype)
@@ -164,7 +165,9 @@ class Decoder(HipModule):
             out = torch.empty(tuple(x.shape[:3]) + (4,), device=x.device, dtype=torch.float32)
             return gn_conv3x3_banded(ctx, x, st, p["g"], p["b"], self.groups, p["co_w"], 4, p["co_b"], out)
         a, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
-        return ops.conv2d(a, p["co_w"], 4, bias=p["co_b"], out_f32=True)  # [n,H,W,4], channel 3 is padding
+        if ops.THIN_OUT:
+            return ops.conv3x3_thin_out(a, p["co_wt"], 4, bias=p["co_b"])  # [n,H,W,4], channel 3 is padding
+        return ops.conv2d(a, p["co_w"], 4, bias=p["co_b"], out_f32=True)
 
 
 class _Cfg(dict):

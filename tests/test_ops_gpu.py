@@ -156,6 +156,60 @@ def test_conv2d(dev, dtype, case):
     assert rel_l2(out, ref) < ACC_TOL
 
 
+THIN_CASES = [
+    # n, H, W, Cin, Cout, stride, pad  — the direct thin-input kernel (csrc/thinconv.hip) behind mimo_conv2d
+    (2, 32, 48, 8, 16, 1, None),       # pose guider conv_in (3 -> 16, Cin padded to 8)
+    (2, 19, 37, 16, 16, 1, None),      # ragged: strips end inside the row, odd height
+    (3, 32, 32, 16, 32, 2, None),      # stride 2
+    (1, 21, 21, 32, 32, 1, None),
+    (2, 16, 20, 32, 96, 2, None),      # 6 of the 8 channel tiles used
+    (1, 24, 40, 8, 128, 1, None),      # VAE encoder conv_in
+    (2, 16, 16, 16, 32, 2, (0, 0)),    # diffusers' asymmetric (0, 1, 0, 1) padding
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_conv2d_thin_input_direct(dev, dtype, case):
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv
+    n, H, W, cin, cout, stride, pad = case
+    x = rnd((n, H, W, cin), dev, dtype, 1)
+    w = rnd((cout, cin, 3, 3), dev, dtype, 2, (cin * 9) ** -0.5)
+    b = rnd((cout,), dev, torch.float32, 3)
+    out_hw = (H // 2, W // 2) if pad == (0, 0) else None
+    ref = torch_conv_ref(x, w, b, 3, stride, pad, out_hw, None)
+    out = ops.conv2d(x, pack_conv(w, dtype), cout, stride=stride, pad=pad, out_hw=out_hw, bias=b, out_f32=True)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert rel_l2(out, ref) < ACC_TOL
+    half = ops.conv2d(x, pack_conv(w, dtype), cout, stride=stride, pad=pad, out_hw=out_hw, bias=b, silu=True)
+    assert half.dtype == dtype and rel_l2(half.float(), F.silu(ref)) < OUT_TOL[dtype]
+    # one image alone gives the bits it has inside the batch
+    one = ops.conv2d(x[-1:].contiguous(), pack_conv(w, dtype), cout, stride=stride, pad=pad, out_hw=out_hw, bias=b, out_f32=True)
+    assert torch.equal(one, out[-1:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 320, 4), (1, 23, 17, 128, 4), (3, 8, 40, 64, 8)])
+def test_conv3x3_thin_out_gemm_plus_tapsum(dev, dtype, shape):
+    """Thin-output convolution as GEMM (input read once, weight regrouped per tap) + mimo_conv3x3_tapsum vs torch and vs the
+    implicit-GEMM kernel."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv, pack_conv_taps
+    n, H, W, cin, cout = shape
+    x = rnd((n, H, W, cin), dev, dtype, 1)
+    w = rnd((cout - 1, cin, 3, 3), dev, dtype, 2, (cin * 9) ** -0.5)   # the last channel is padding
+    b = torch.cat([rnd((cout - 1,), dev, torch.float32, 3), torch.zeros(1, device=dev)])
+    ref = torch_conv_ref(x, w, b[:-1], 3, 1, None, None, None)
+    out = ops.conv3x3_thin_out(x, pack_conv_taps(w, dtype, cout_pad=cout), cout, bias=b)
+    assert out.shape == (n, H, W, cout) and out.dtype == torch.float32
+    assert rel_l2(out[..., :-1], ref) < ACC_TOL and float(out[..., -1].abs().max()) == 0.0
+    old = ops.conv2d(x, pack_conv(w, dtype, cout_pad=cout), cout, bias=b, out_f32=True)
+    assert rel_l2(out, old) < ACC_TOL
+    one = ops.conv3x3_thin_out(x[-1:].contiguous(), pack_conv_taps(w, dtype, cout_pad=cout), cout, bias=b)
+    assert torch.equal(one, out[-1:])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_resblock_epilogue_and_fused_shortcut(dev, dtype):
     """conv2 of a ResBlock: 3x3 over h + fused 1x1 shortcut over x + per-image temb-style bias + fp32 residual."""
