@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32, banded, gn_conv3x3_banded
+from .modules import Ctx, Downsample, HipModule, ResnetBlock, Upsample, _f32, banded, gn_conv3x3_banded, row_bands
 from .packing import pack_conv, pack_conv_taps, pad_vec
 
 
@@ -163,7 +163,18 @@ class Decoder(HipModule):
         if banded(ctx, x.shape[1], x.shape[2]):
             st = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
             out = torch.empty(tuple(x.shape[:3]) + (4,), device=x.device, dtype=torch.float32)
-            return gn_conv3x3_banded(ctx, x, st, p["g"], p["b"], self.groups, p["co_w"], 4, p["co_b"], out)
+            if not ops.THIN_OUT:
+                return gn_conv3x3_banded(ctx, x, st, p["g"], p["b"], self.groups, p["co_w"], 4, p["co_b"], out)
+            # per (image, row band) with one halo row above and below: the tap GEMM is per pixel and the gather sums the nine
+            # contributions in a fixed order, so the interior rows of a band carry the bits of the untiled launch (the band's
+            # own edge rows see zero padding where the image continues: they are computed and dropped)
+            n, H = x.shape[0], x.shape[1]
+            for i in range(n):
+                for y0, y1 in row_bands(H, ctx.band_rows):
+                    lo, hi = max(0, y0 - 1), min(H, y1 + 1)
+                    a, _ = ops.group_norm_apply(x[i:i + 1, lo:hi], st[i:i + 1], p["g"], p["b"], groups=self.groups, silu=True, dtype=ctx.dtype)
+                    out[i:i + 1, y0:y1] = ops.conv3x3_thin_out(a, p["co_wt"], 4, bias=p["co_b"])[:, y0 - lo:y0 - lo + (y1 - y0)]
+            return out
         a, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
         if ops.THIN_OUT:
             return ops.conv3x3_thin_out(a, p["co_wt"], 4, bias=p["co_b"])  # [n,H,W,4], channel 3 is padding
