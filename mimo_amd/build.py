@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False, tune: bool = False) -> str
     os.makedirs(objdir, exist_ok=True)
     flags = FLAGS + (["-DMIMO_TUNE"] if tune else [])
     lib_path = TUNE_LIB_PATH if tune else LIB_PATH
-    headers = [os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "mimo_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.hip.h", "gemm_stream.hip.h", "thinconv.hip.h")] + [os.path.join(INCLUDE, "mimo_hip.h")]
     jobs = []
     objs = []
     for s in SOURCES:

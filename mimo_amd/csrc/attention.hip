@@ -14,7 +14,7 @@
 // (q = lane & 31): the online-softmax max/sum are in-lane reductions plus one xor-32
 // shuffle, the O rescale needs no broadcast, and P feeds the second MFMA straight from the
 // accumulator registers (the k-index permutation is applied identically to V^T's fragment).
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

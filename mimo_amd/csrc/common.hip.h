@@ -1,4 +1,4 @@
-// common.cuh — shared device helpers for the gfx950 kernels of libmimo_hip.so.
+// common.hip.h — shared device helpers for the gfx950 kernels of libmimo_hip.so.
 // CDNA4 only: wave = 64 lanes, MFMA 16x16x32 / 32x32x16 (f16|bf16 in, f32 accumulate).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 // elementwise.hip — boundary layout conversions and the fused per-step latent update.
 // Reference ops replaced: see include/mimo_hip.h.  All HBM-bound, tiny tensors
 // (latents are 0.4 MB per 24-frame window); one thread per element, grid-stride.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

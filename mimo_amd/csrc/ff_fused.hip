@@ -28,7 +28,7 @@
 // Pipeline: ONE barrier per step.  FF2 of chunk c runs in step c + 1 (its W2 slice is streamed one step behind the W1
 // tile, the partner's half of the chunk was written before the barrier).  Only the half-1 waves issue the DMAs, which
 // shifts them behind their SIMD partners: one wave's GELU (VALU) and DMA issue sit under the other's MFMAs.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

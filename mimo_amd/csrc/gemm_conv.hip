@@ -22,9 +22,9 @@
 // with 4 consecutive output columns of one row -> 16-byte epilogue loads/stores.
 #include <stdlib.h>
 
-#include "common.cuh"
-#include "gemm_stream.cuh"
-#include "thinconv.cuh"
+#include "common.hip.h"
+#include "gemm_stream.hip.h"
+#include "thinconv.hip.h"
 
 namespace {
 

@@ -22,8 +22,8 @@
 // Memory-operation accounting (per wave, in issue order): ... DMA(t) | stores(t-2) | DMA(t+1) | stores(t-1) | ...
 // so "tile t has landed" is a COUNTED s_waitcnt vmcnt at the top of step t (vmcnt retires in order on gfx9).
 // The bias lives in LDS (ds_read, not a vector-memory load) so that the epilogue adds no loads to that queue.
-#include "common.cuh"
-#include "gemm_stream.cuh"
+#include "common.hip.h"
+#include "gemm_stream.hip.h"
 
 namespace mimo_stream {
 namespace {

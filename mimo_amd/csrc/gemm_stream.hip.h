@@ -1,4 +1,4 @@
-// gemm_stream.cuh — internal interface between gemm_conv.hip (launcher) and gemm_stream.hip (kernel).
+// gemm_stream.hip.h — internal interface between gemm_conv.hip (launcher) and gemm_stream.hip (kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

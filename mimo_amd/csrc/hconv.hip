@@ -24,7 +24,7 @@
 // SOURCE address (the DMA writes lane-linear), the patch image on the ds_write address.
 // Every vector-memory instruction of the main loop is inline asm and counted by hand (s_waitcnt vmcnt): hipcc drains
 // the DMA queue before LDS reads it cannot prove independent.
-#include "common.cuh"
+#include "common.hip.h"
 
 // Compile-time experiment knobs (tools/hconv_variants.py builds one small library per setting and times them interleaved
 // in one process; the shipped library is built with the defaults below).

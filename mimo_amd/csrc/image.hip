@@ -17,7 +17,7 @@
 //     occluder re-imposition (float64, as numpy: `occ / 255.0`) -> overlap cross-fade with the previous clip's frame
 //     (float64) -> truncation to uint8.  Every arithmetic step is a separately rounded IEEE operation in numpy's order and
 //     width (no FMA contraction), so the uint8 result equals the reference's.
-#include "common.cuh"
+#include "common.hip.h"
 
 // numpy rounds every multiply and add separately: no FMA contraction anywhere in this file.  The arithmetic below is
 // written with plain operators ON PURPOSE: the pragma governs expressions in this file, whereas the __fmul_rn / __dadd_rn

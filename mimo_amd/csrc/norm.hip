@@ -6,7 +6,7 @@
 // are one-pass SHIFTED sums (shift = the group's first element) or, when the producing GEMM / convolution
 // emitted column statistics in its epilogue, a merge of those (gn_stats_cols_kernel: no pass over the
 // tensor at all); LayerNorm is two-pass (mean, then centred variance) on a row held in registers.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

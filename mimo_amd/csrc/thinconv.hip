@@ -21,8 +21,8 @@
 //   * no barrier after the weight load: waves are independent, many blocks per CU hide the load latency.
 // Epilogue: bias, optional SiLU, out_scale, half or fp32 output (what these layers use; anything else stays on the
 // implicit-GEMM kernel).
-#include "common.cuh"
-#include "thinconv.cuh"
+#include "common.hip.h"
+#include "thinconv.hip.h"
 
 namespace mimo_thin {
 namespace {

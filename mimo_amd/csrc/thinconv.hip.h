@@ -1,4 +1,4 @@
-// thinconv.cuh — internal interface between gemm_conv.hip (the mimo_conv2d launcher) and thinconv.hip (kernel).
+// thinconv.hip.h — internal interface between gemm_conv.hip (the mimo_conv2d launcher) and thinconv.hip (kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -676,12 +676,12 @@ def test_interpolate_latents_matches_reference():
 
 
 def test_gelu_polynomial_constants():
-    """common.cuh's GELU: max(x, 0) - |x| 2^P(|x|) with P a degree-7 polynomial (the Gaussian tail's log2).  The constants are
+    """common.hip.h's GELU: max(x, 0) - |x| 2^P(|x|) with P a degree-7 polynomial (the Gaussian tail's log2).  The constants are
     read from the header and evaluated in float32 the way the kernel does (Horner, clamp at 6): absolute error against the
     erf form of torch's F.gelu below 3.5e-7 over [-12, 12], zero at zero, identity for large x."""
     import numpy as np
     from scipy.special import erf
-    src = open(os.path.join(ROOT, "mimo_amd", "csrc", "common.cuh")).read()
+    src = open(os.path.join(ROOT, "mimo_amd", "csrc", "common.hip.h")).read()
     m = re.search(r"GELU_P\[8\] = \{([^}]*)\}", src)
     assert m, "GELU_P not found"
     c = np.array([float(v.strip().rstrip("f")) for v in m.group(1).split(",")], dtype=np.float32)
