@@ -79,6 +79,26 @@ def main():
         for s in (s1, s2):
             cur.wait_stream(s)
 
+    def unit(cond):
+        blocks = unet.spatial_blocks()
+        saved = [b.bank_kv for b in blocks]
+        if not cond:
+            for b in blocks:
+                b.bank_kv = None
+        try:
+            unet.run_tokens(xs[0], 499, ehs[1:] if cond else ehs[:1], 1, 24, poses[0])
+        finally:
+            for b, kv in zip(blocks, saved):
+                b.bank_kv = kv
+
+    with ops.split_k(False):
+        # the items of pipeline.plan_items: a whole window (b = 2) and its CFG halves as b = 1 forwards (pipeline._run_unit)
+        best = [1e9, 1e9, 1e9]
+        for _ in range(3):
+            for i, fn in enumerate((batched, lambda: unit(True), lambda: unit(False))):
+                best[i] = min(best[i], timed(fn))
+        print(f"unit costs (split-K off, as in the sharded mode): window b=2 {best[0]:.2f} ms | cond half b=1 {best[1]:.2f} ms "
+              f"({best[1]/best[0]:.3f}) | uncond half b=1 {best[2]:.2f} ms ({best[2]/best[0]:.3f})", flush=True)
     with ops.split_k(False):
         print(f"two windows (b = 2 each): sequential {timed(two_batched_seq):.2f} ms | on two streams {timed(two_batched_conc):.2f} ms", flush=True)
     with ops.split_k(False):  # the split-K workspace is shared: not safe across concurrent streams
