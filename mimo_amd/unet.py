@@ -198,7 +198,11 @@ class UNetBase(HipModule):
     def timestep_table(self, timesteps, b):
         """Sinusoidal embeddings (Timesteps(flip_sin_to_cos, shift 0)) of a clip's timesteps as ONE half tensor
         [len(timesteps), b, C0], built on the host and uploaded once: run_tokens(t_emb=table[i]) then launches no
-        elementwise glue per step.  Same formula and fp32 arithmetic as the per-call path of _time_and_cross."""
+        elementwise glue per step.  Same formula and fp32 arithmetic as the per-call path of _time_and_cross — but THIS table
+        takes exp / cos / sin from the host's libm (as the CPU oracle does) and the per-call path from the device's: the two
+        can differ by one fp32 ulp before the rounding to half, i.e. by half an ulp in a few of the 320 entries (8 at
+        t = 999).  The pipeline — eager or replaying a hipGraph — always goes through the tables (clip_tables), so its runs
+        agree bit for bit; only a direct run_tokens(x, timestep, ...) call takes the device formula."""
         import math
         half = self.boc[0] // 2
         freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)

@@ -362,7 +362,7 @@ def _rccl_world1_worker(port, q, F):
         dist.destroy_process_group()
 
 
-def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0, force=False):
+def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0, force=False, graphs=False):
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -380,6 +380,7 @@ def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, de
     pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
     pipe.shard_windows, pipe.batch_invariant = shard, invariant
     pipe.shard_force = force
+    pipe.use_graphs = graphs
     if window_streams is not None:
         pipe.window_streams = window_streams
     if delay_main_cycles:  # the main stream falls far behind the host: whatever a side stream needs from it must be ordered by events
@@ -402,6 +403,19 @@ def test_window_streams_do_not_change_the_result(dev):
     # launches are issued — only the wait_stream(main) events keep the result right.
     delayed = _small_clip(dev, window_streams=2, delay_main_cycles=4e8)
     assert torch.equal(one, delayed)
+
+
+def test_hipgraph_replay_of_the_forward_matches_the_eager_run(dev):
+    """pipe.use_graphs (bench.py --graphs): the denoising forward of a (batch, window) shape is captured once as a hipGraph and
+    replayed per step.  The captured forward consumes the same per-step rows of the clip tables (time-embedding projections,
+    collapsed cross-attentions) as the eager run and launches the same kernels on the same buffers: bit-identical, replay
+    after replay, one window and two."""
+    for F in (24, 26):
+        eager = _small_clip(dev, F=F, window_streams=1)
+        graph = _small_clip(dev, F=F, graphs=True)
+        again = _small_clip(dev, F=F, graphs=True)
+        assert torch.isfinite(graph).all() and torch.equal(graph, again)
+        assert torch.equal(graph, eager)
 
 
 @pytest.mark.parametrize("world,F", [(2, 26), (2, 24), (2, 50), pytest.param(4, 26, marks=pytest.mark.skipif(
