@@ -97,6 +97,22 @@ def main():
         for _ in range(3):
             for i, fn in enumerate((batched, lambda: unit(True), lambda: unit(False))):
                 best[i] = min(best[i], timed(fn))
+        def window_plus_half(conc):  # what the busiest rank of plan_items(10 windows, 8 ranks) runs per step
+            cur = torch.cuda.current_stream()
+            if not conc:
+                batched()
+                unit(True)
+                return
+            for s in (s1, s2):
+                s.wait_stream(cur)
+            with torch.cuda.stream(s1), ops.workspace_slot(0):
+                batched()
+            with torch.cuda.stream(s2), ops.workspace_slot(1):
+                unit(True)
+            for s in (s1, s2):
+                cur.wait_stream(s)
+        wp = [min(timed(lambda: window_plus_half(False)) for _ in range(2)), min(timed(lambda: window_plus_half(True)) for _ in range(2))]
+        print(f"busiest rank at 8 GPUs (one window b=2 + one cond half b=1): back to back {wp[0]:.2f} ms | on two streams {wp[1]:.2f} ms", flush=True)
         print(f"unit costs (split-K off, as in the sharded mode): window b=2 {best[0]:.2f} ms | cond half b=1 {best[1]:.2f} ms "
               f"({best[1]/best[0]:.3f}) | uncond half b=1 {best[2]:.2f} ms ({best[2]/best[0]:.3f})", flush=True)
     with ops.split_k(False):
