@@ -729,3 +729,46 @@ def test_fused_block_weight_packings():
     ws = pack_block_tail_stream(wp, w1p, wp, torch.float32)
     assert ws.shape == (10 * C, C) and ws.shape[0] == 50 * 64
     assert torch.equal(ws[:C], rows) and torch.equal(ws[C:9 * C], pack_ff2_kperm(w1p, torch.float32)) and torch.equal(ws[9 * C:], tail)
+
+
+def test_pack_conv_taps_restates_a_3x3_convolution():
+    """packing.pack_conv_taps regroups a 3x3 weight as [9 Cout, Cin] (row (3 ky + kx) Cout + c) so that a thin-output
+    convolution is ONE GEMM over the pixels (every pixel's contribution to the nine outputs around it) followed by
+    mimo_conv3x3_tapsum's gather out[y, x, c] = bias[c] + sum_taps T[y + ky - 1, x + kx - 1][tap][c].  Here in fp32 on the host
+    against torch's conv2d, including the zero-padded output channel and the fixed tap order."""
+    from mimo_amd.packing import pack_conv, pack_conv_taps
+    g = torch.Generator().manual_seed(5)
+    n, H, W, cin, cout, cpad = 2, 7, 9, 24, 3, 4
+    x = torch.randn(n, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    wt = pack_conv_taps(w, torch.float32, cout_pad=cpad)
+    assert wt.shape == (9 * cpad, cin)
+    # row tap * cpad + c of the tap matrix = column block `tap` of row c of the packed implicit-GEMM weight
+    wp = pack_conv(w, torch.float32, cout_pad=cpad)
+    for tap in range(9):
+        assert torch.equal(wt[tap * cpad:(tap + 1) * cpad], wp[:, tap * cin:(tap + 1) * cin])
+    T = (x.reshape(-1, cin) @ wt.t()).view(n, H, W, 9, cpad)
+    out = torch.zeros(n, H, W, cpad)
+    out[..., :cout] += b
+    for ky in range(3):
+        for kx in range(3):
+            ys, xs = slice(max(0, 1 - ky), min(H, H + 1 - ky)), slice(max(0, 1 - kx), min(W, W + 1 - kx))
+            yt, xt = slice(max(0, ky - 1), min(H, H + ky - 1)), slice(max(0, kx - 1), min(W, W + kx - 1))
+            out[:, ys, xs] += T[:, yt, xt, ky * 3 + kx]
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(out[..., :cout], ref, atol=1e-4) and float(out[..., cout:].abs().max()) == 0.0
+
+
+def test_statistics_side_outputs_are_decided_by_the_image_size_only():
+    """Which producers attach GroupNorm statistics must not depend on the batch (a sharded unit and the full launch of a
+    window have to produce the same bits): the decisions are functions of the rows per image."""
+    from mimo_amd import ops
+    dev = torch.device("cpu")
+    for hw in (64, 1024, 4096):
+        shapes = {ops._tail_colstats(hw, hw * nimg, 320, dev) is not None for nimg in (1, 2, 24, 48)}
+        assert len(shapes) == 1
+        assert {ops._want_colstats(hw, hw * nimg) for nimg in (1, 2, 24, 48)} in ({True}, {False})
+    assert ops._tail_colstats(4096, 4096 * 48, 320, dev).shape == (4096 * 48 // 32, 2, 320)
+    assert ops._tail_colstats(100, 4800, 320, dev) is None      # slabs of 32 rows would straddle images
+    assert ops._tail_colstats(False, 4096, 320, dev) is None
