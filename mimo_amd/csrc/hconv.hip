@@ -24,6 +24,10 @@
 // SOURCE address (the DMA writes lane-linear), the patch image on the ds_write address.
 // Every vector-memory instruction of the main loop is inline asm and counted by hand (s_waitcnt vmcnt): hipcc drains
 // the DMA queue before LDS reads it cannot prove independent.
+//
+// Side outputs: the half cast of the raw input (the operand of conv2's fused 1x1 shortcut), and GroupNorm statistics of the
+// tensor the launch writes (see HArgs::tstats), merged by mimo_group_norm_stats_slabs: the norm that consumes the output
+// makes no statistics pass over HBM.
 #include "common.hip.h"
 
 // Compile-time experiment knobs (tools/hconv_variants.py builds one small library per setting and times them interleaved
@@ -65,7 +69,9 @@ struct HArgs {
   const float* img_bias;  // [n / imgs_per_bias_row][ldib] or null
   const float* res;       // fp32 [n, H, W, N] or null
   uint16_t* raw;          // optional side output: half16 cast of the un-normalised input [n, H, W, C]
-  float* tstats;          // optional side output: per (16 x 16 tile, output channel) mean and centred sum of squares [tiles][2][N]
+  float* tstats;          // optional side output, GroupNorm statistics of `out` as (mean, centred sum of squares) per channel:
+                          //   without a residual per 16 x 16 tile [tiles][2][N] (from the accumulators, TSTATS = 1),
+                          //   with one per 32-pixel slab = two tile rows [n H W / 32][2][N] (in the store loop, TSTATS = 2)
   int64_t ldw, ldib;
   int C1, C2, n, H, Wd, Hs, Ws, ups, N, tiles_n, tiles_x, tiles_y, silu, epi_silu, imgs_per_bias_row;
   float out_scale;
