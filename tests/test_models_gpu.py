@@ -234,7 +234,8 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
     report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W)
-    assert e_lat < {torch.float16: 1.85e-3, torch.bfloat16: 1.5e-2}[dtype]  # measured 1.41e-3 / 1.1e-2 (x 1.3)
+    # CFG at guidance 3.5: 2e-3 (see test_pipeline_edge_cases_vs_oracle for the bound and the bisect); bf16 carries 8x the rounding
+    assert e_lat < {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype] and e_vid < {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype]
 
 
 @pytest.mark.parametrize("F,guidance,hw", [(1, 3.5, 64), (5, 1.0, 64), (24, 1.0, 40), (3, 3.5, 104)])
@@ -265,7 +266,13 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
     report(f"pipeline edge F={F} guidance={guidance} {hw}x{hw} fp16: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W) and bool(torch.isfinite(vid_p).all())
-    assert e_lat < 2.0e-3 and e_vid < 3.0e-3  # the half-width models' two-step figures (1.4e-3 / 1.0e-3 at F = 26) with headroom
+    # Bars, not measurements: 1e-3 without CFG.  With guidance w the step combines u + w (c - u): the two branches' rounding
+    # errors enter with weights (1 - w) and w while the result stays of the size of one branch (these random-weight models barely
+    # react to the CLIP embedding), i.e. up to sqrt(w^2 + (w - 1)^2) = 4.3x at w = 3.5 for independent errors — 2e-3.  The
+    # bisect (profiles/r4_edge_case_bisect.txt: the same runs fed the ORACLE's VAE latents and pose features) shows the
+    # 1.2-1.6e-3 of the CFG cases is this, not the VAE or the pose guider: exact inputs leave it unchanged, guidance 1 gives 6.8e-4.
+    bar = 1.0e-3 if guidance == 1.0 else 2.0e-3
+    assert e_lat < bar and e_vid < bar
 
 
 def test_pipeline_rejects_what_the_reference_cannot_run(dev):
@@ -620,4 +627,4 @@ def test_pipeline_call_surface_pil_inputs(dev):
                             torch.stack([to_t(p) for p in poses]), lat, 2, 3.5)
     e = rel_l2(out, vid_o)
     report(f"pipeline __call__ (PIL inputs, HIP CLIP, per-frame backgrounds) fp16: video rel_l2={e:.2e}")
-    assert e < 1.4e-3  # measured 1.06e-3 (x 1.3)
+    assert e < 2.0e-3  # CFG at guidance 3.5 on the half-width models: the bound of test_pipeline_edge_cases_vs_oracle
