@@ -6,6 +6,7 @@ Activation convention: channels-last token-major.  An image batch is a contiguou
 fp16/bf16 ("half16").
 """
 import ctypes
+import threading
 
 import torch
 
@@ -96,7 +97,9 @@ def split_k_enabled():
 
 
 _WS = {}
-_WS_SLOT = 0
+
+
+_TLS = threading.local()  # workspace slot / base of the calling host thread (two threads may drive two pipelines)
 
 
 class workspace_slot:
@@ -107,12 +110,25 @@ class workspace_slot:
         self.slot = slot
 
     def __enter__(self):
-        global _WS_SLOT
-        self.prev, _WS_SLOT = _WS_SLOT, self.slot
+        self.prev, _TLS.slot = getattr(_TLS, "slot", 0), self.slot
 
     def __exit__(self, *a):
-        global _WS_SLOT
-        _WS_SLOT = self.prev
+        _TLS.slot = self.prev
+        return False
+
+
+class workspace_base:
+    """Shifts every workspace slot chosen inside the block by `base`: two pipelines that run concurrently on different streams
+    (bench.py --clips-in-flight 2) each use their own set of split-K scratch buffers."""
+
+    def __init__(self, base):
+        self.base = base
+
+    def __enter__(self):
+        self.prev, _TLS.base = getattr(_TLS, "base", 0), self.base
+
+    def __exit__(self, *a):
+        _TLS.base = self.prev
         return False
 
 
@@ -122,7 +138,7 @@ def _workspace(device):
     share a slot are issued on one stream at a time (during hipGraph capture: the capture stream), so stream order makes
     sharing safe; concurrent streams take different slots (workspace_slot)."""
     dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (dev, _WS_SLOT)
+    key = (dev, getattr(_TLS, "base", 0) + getattr(_TLS, "slot", 0))
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(L.load().mimo_workspace_bytes() // 4, device=device, dtype=torch.float32)
