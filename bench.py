@@ -365,8 +365,71 @@ def shard_plan(a, frames, world):
                                          "exposed_gather_ms = HIP-event time of the final exchange wait per clip"}}
 
 
+def emulate_world(a, dev, dtype):
+    """--emulate-world W (one GPU): the long-clip mode's per-rank schedule MEASURED instead of modelled.  For every rank k of a
+    W-GPU job over a W x 24-frame clip, this GPU runs exactly what rank k would run per clip — CLIP, reference UNet, its chunk
+    of the per-frame stages, its work items of every denoising step on two streams, the slot-wise all_gather calls (on a
+    world-1 RCCL group: launch path and stream hand-over are real, the xGMI transfer of (W - 1) x 1.5 MB per slot is not),
+    the canonical-order accumulation of all units and the DDIM step — and the same clip is timed unsharded on one GPU.
+    The busiest rank's time bounds the W-GPU step: speed-up <= single / max_k, before box-to-box spread and link time."""
+    import torch.distributed as dist
+    from mimo_amd.context import get_context_scheduler
+    from mimo_amd.pipeline import plan_items
+    W = a.emulate_world
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29677", rank=0, world_size=1, device_id=dev)
+    pipe = build_pipeline(dev, dtype)
+    frames = a.frames * W
+    inp = synthetic_inputs(dev, frames, a.size, seed=42)
+    cfg = a.guidance > 1.0
+    nw = len(get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4))
+    items = plan_items(nw, cfg, W)
+
+    def clip():
+        emb = pipe.image_encoder(inp["clip_pixels"].to(dtype)).image_embeds
+        return pipe.run_tensors(inp["ref_image"], inp["bk_images"], inp["pose_images"], emb, inp["latents"], a.ddim_steps, a.guidance)
+
+    def timed(n=1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            v = clip()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(v).all())
+        return (time.perf_counter() - t0) / n * 1e3
+
+    per_rank = []
+    pipe.shard_windows = True
+    for k in range(W):
+        pipe.shard_emulate = (k, W)
+        if k == 0:
+            clip()  # warm-up (packing, allocator pools)
+        pipe.stage_times = {}
+        clip()
+        st, pipe.stage_times = pipe.stage_times, None
+        ms = timed(1)
+        per_rank.append({"rank": k, "items": [("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in items[k]],
+                         "ms_per_clip": round(ms, 1), "stage_ms": {n: round(v, 1) for n, v in st.items()}})
+    pipe.shard_windows, pipe.shard_emulate = False, None
+    clip()
+    single = timed(1)
+    pipe.batch_invariant = True   # split-K off: the arithmetic the sharded ranks run (bit-identical result)
+    clip()
+    single_bi = timed(1)
+    worst = max(r["ms_per_clip"] for r in per_rank)
+    print(json.dumps({"emulate_world": W, "frames": frames, "windows": nw, "size": a.size, "ddim_steps": a.ddim_steps, "dtype": a.dtype,
+                      "per_rank": per_rank, "busiest_rank_ms": worst, "single_gpu_ms": round(single, 1),
+                      "single_gpu_split_k_off_ms": round(single_bi, 1),
+                      "speedup_bound_vs_single": round(single / worst, 2), "speedup_bound_vs_single_split_k_off": round(single_bi / worst, 2),
+                      "note": "one GPU measured every rank's share in turn; collectives ran on a world-1 RCCL group (no xGMI time), "
+                              "other ranks' results are stand-ins; excludes box-to-box spread", "library_sha256_16": lib_hash()}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--emulate-world", type=int, default=0, help="one GPU: measure every rank's share of a W-GPU long-clip job "
+                    "(--shard-windows schedule) in turn, and the same clip unsharded; prints the per-rank table as one JSON line")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed clips")
     ap.add_argument("--warmup", type=int, default=1, help="untimed clips")
@@ -414,6 +477,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    if a.emulate_world > 1:
+        emulate_world(a, dev, dtype)
+        return
 
     from mimo_amd import ops
     pipe = build_pipeline(dev, dtype)
@@ -528,7 +594,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": min(os.cpu_count(), 32), "kind": "port",
                                        "sample": f"not measured within {240 if a.cpu_baseline_quick else 600} s: {type(e).__name__}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
     # under rocprofv3 the interpreter can hang in teardown after the tool has written its output: leave after 60 s
     import threading

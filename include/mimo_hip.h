@@ -286,6 +286,27 @@ int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* 
                           const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1, const void* W2,
                           const float* b2, const float* bp, const float* x, int64_t ldx, float* out, int64_t ldo,
                           int64_t M, int C, float* colstats, void* stream);
+/* Everything a transformer block does BEFORE its attention core in one launch (round 5): the projection that produces the
+ * token stream, the LayerNorm in front of the attention and the fused Q/K/V projection —
+ *   spatial block:   GroupNorm -> proj_in (Transformer3DModel.forward, src/models/transformer_3d.py:118-140) -> norm1
+ *                    (TemporalBasicTransformerBlock.forward, src/models/attention.py:329-360 /
+ *                    mutual_self_attention.py:118-120) -> attn1.to_q / to_k / to_v
+ *   motion module:   GroupNorm -> proj_in (TemporalTransformer3DModel.forward, src/models/motion_module.py:150-163) -> norms[0]
+ *                    + positional encoding -> attention_blocks[0].to_q/k/v (:230-248, :300-330); and for the second attention
+ *                    attention_blocks[0].to_out + residual -> norms[1] + PE -> attention_blocks[1].to_q/k/v
+ *   y[M, C] (fp32)  = (residual +) A' @ Wi^T + bi                      (written: the residual of the attention's to_out)
+ *   qkv[M, 3C] (half) = (LayerNorm(y) * ln_gamma + ln_beta (+ ln_pe[(m / ln_rows_per_frame) % ln_pe_frames])) @ Wqkv^T
+ *   A' = A (half16 [M, lda]: an attention output), or — A == NULL — half(x32 * a + b) with x32 the fp32 block input and
+ *   gn_ab = fp32 [M / rows_per_img, 2, C] the GroupNorm folded to a per-(image, channel) affine (mimo_group_norm_affine):
+ *   the normalised tensor never reaches memory (rows_per_img % 128 == 0: a 128-row panel lies inside one image).
+ *   Wstream: half16 [4C, C] = [Wi with rows in tile order (pack_rows_tail) | [Wq; Wk; Wv] with its K axis permuted
+ *   (pack_ff2_kperm)] (mimo_amd.packing.pack_block_head_stream); the LayerNorm output never reaches memory.
+ *   ln_pe: NULL or fp32 [ln_pe_frames, C], ln_rows_per_frame % 128 == 0.  MIMO_EINVAL unless C == 320. */
+int mimo_block_head_fused(int dtype, const void* A, int64_t lda, const float* x32, int64_t ldx, const float* gn_ab,
+                          int64_t rows_per_img, const void* Wstream, const float* bi, const float* residual, int64_t ldr,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,
+                          int64_t ln_rows_per_frame, int ln_pe_frames, float* y_out, int64_t ldy, void* qkv, int64_t ldq,
+                          int64_t M, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Spatial multi-head attention (flash, online softmax, MFMA 32x32x16) with an optional

@@ -6,7 +6,11 @@
 //   2  mimo_block_tail_fused y = res + O @ Wo^T + bo (+ img_bias);  n = LayerNorm(y);  out32 = x + (y + FF(n)) @ Wp^T + bp
 //                            (+ the attention's to_out, its residual, the collapsed cross-attention vector and the LayerNorm)
 //
-// The feed-forward core, which the other two wrap with projection steps on the same weight stream (see MODE below):
+//   3  mimo_block_head_fused  y = (res +) A @ Wi^T + bi;  n = LayerNorm(y) (+ pe[frame]);  qkv = n @ Wqkv^T   (A half)
+//   4  (same entry point)     A = half(x * ga[img] + gb[img]): the GroupNorm in front of proj_in applied while the fp32
+//                             block input is loaded (round 5: everything a transformer block does BEFORE its attention core)
+//
+// The feed-forward core, which the other modes wrap with projection steps on the same weight stream (see MODE below):
 //
 // replaces diffusers FeedForward(GEGLU, Linear) + the residual add of src/models/attention.py:428-429 /
 // motion_module.py:258 as two launches (mimo_gemm GEGLU, then mimo_gemm + residual) with the [M, 4C] intermediate
@@ -63,6 +67,13 @@ struct FFArgs {
   const float* ln_beta;   // [C]
   int64_t ldib, rows_per_img;
   float ln_eps;
+  // MODE 3 / 4 (block head): W1 = ONE stream of 20 tiles of 64 rows [Wi (rows in tile order, K natural) | Wqkv (rows natural,
+  // K permuted)]; A (half, MODE 3) or x + gn_ab (MODE 4) = the operand of the first projection; res optional; out32 = y;
+  // out = qkv (half [M, ldo], 3C columns)
+  const float* gn_ab;     // MODE 4: fp32 [nimg, 2, C] GroupNorm folded to x * a + b per (image, channel); rows_per_img % 128 == 0
+  const float* ln_pe;     // optional fp32 [ln_pe_frames, C] added to the LayerNorm output, row = (m / ln_rows_per_frame) % frames
+  int64_t ln_rows_per_frame;
+  int ln_pe_frames;
 #ifdef MIMO_TUNE
   unsigned long long* dbg;  // phase trace (tools/ff_trace.py) or null
   int ablate;               // 1: no DMAs (stale tiles); 2: no MFMA phases (stream + barriers only); 3: GELU -> identity
@@ -113,9 +124,12 @@ __device__ __forceinline__ unsigned pinned(unsigned v) {
 // the LayerNorm in front (the whole tail of a transformer block after its attention core)
 template <int DT, int MODE>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
-  constexpr bool TAIL = MODE >= 1;
-  constexpr int NPRE = MODE == 2 ? NTAIL : 0;           // W tiles of the folded attention output projection
-  constexpr int NPOS = NPRE + NSTEP + (TAIL ? NTAIL : 0);   // stream positions (W tiles of the W1 region) per panel
+  constexpr bool HEAD = MODE >= 3;                      // block head: projection -> LayerNorm -> QKV, no feed-forward
+  constexpr bool TAIL = MODE == 1 || MODE == 2;
+  constexpr int NPRE = MODE >= 2 ? NTAIL : 0;           // W tiles of the folded leading projection (to_out | proj_in)
+  constexpr int NFF = HEAD ? 0 : NSTEP;                 // feed-forward positions
+  constexpr int NQKV = 3 * C / 64;                      // block head: W tiles of the fused QKV projection
+  constexpr int NPOS = NPRE + NFF + (TAIL ? NTAIL : 0) + (HEAD ? NQKV : 0);   // stream positions (W tiles of the W1 region) per panel
   __shared__ __attribute__((aligned(16))) uint4 smem[LDS_BYTES / 16];  // ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   for (int n = tid; n < C; n += 512) bias_lds[8 * C + n] = g.b2 ? g.b2[n] : 0.f;
   for (int n = tid; n < C; n += 512) bias_lds[9 * C + n] = (TAIL && g.bp) ? g.bp[n] : 0.f;
   for (int n = tid; n < C; n += 512) {
-    bias_lds[10 * C + n] = (MODE == 2 && g.bo) ? g.bo[n] : 0.f;
-    bias_lds[11 * C + n] = MODE == 2 ? g.ln_gamma[n] : 0.f;
-    bias_lds[12 * C + n] = MODE == 2 ? g.ln_beta[n] : 0.f;
+    bias_lds[10 * C + n] = (MODE >= 2 && g.bo) ? g.bo[n] : 0.f;
+    bias_lds[11 * C + n] = MODE >= 2 ? g.ln_gamma[n] : 0.f;
+    bias_lds[12 * C + n] = MODE >= 2 ? g.ln_beta[n] : 0.f;
   }
 
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
     return r;
   };
-  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(MODE == 2 ? NPOS * 64 : 8 * C) * (unsigned)ROWB1);
+  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(MODE >= 2 ? NPOS * 64 : 8 * C) * (unsigned)ROWB1);
   const i32x4 rW2 = make_rsrc(g.W2, (unsigned)C * (unsigned)(HID * 2));
   const i32x4 rWp = make_rsrc(MODE == 1 ? g.Wp : g.W1, MODE == 1 ? (unsigned)C * (unsigned)ROWB1 : 0u);
   constexpr unsigned OOBA = 0x80000000u;
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       const bool live1 = ld_t < total;
       const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;      // position ld_t - 1 inside its panel
       // (only the feed-forward positions have a W2 slice)
-      const bool live2 = ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NSTEP);
+      const bool live2 = NFF > 0 && ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NFF);
       const unsigned dst1 = smem_base + (ld_t & 1u) * (unsigned)STAGE;
       const unsigned dst2 = smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE;
       // MODE 2: the W1 region's tiles are one stream in position order; MODE 1: the projection tiles are a second tensor
@@ -220,8 +234,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)const_cast<uint16_t*>(g.A + M0 * g.lda), 0, (int)(((rows_valid - 1) * g.lda + C) * 2), 0x00020000);
+    // (a block head may have no residual: zero records, every load returns 0)
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)const_cast<float*>(g.res + M0 * g.ldr), 0, (int)(((rows_valid - 1) * g.ldr + C) * 4), 0x00020000);
+        (void*)const_cast<float*>(g.res ? g.res + M0 * g.ldr : nullptr), 0, g.res ? (int)(((rows_valid - 1) * g.ldr + C) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + C) * 2), 0x00020000);
     // ---- this row group's 32 x 320 slice of A in MFMA operand layout (both column halves hold it) ----
@@ -235,7 +250,69 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         for (int ks = 0; ks < KS; ++ks)
           fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, 0));
     };
-    if constexpr (MODE != 2) load_a();   // (MODE 2 loads it after the per-image vector: 80 registers fewer in flight)
+    if constexpr (MODE == 4) {
+      // ---- block head on the fp32 block input: the GroupNorm in front of proj_in, folded to x * a + b per (image, channel),
+      // is applied while the operand is loaded.  a, b of the panel's image (a panel lies inside one image: rows_per_img % 128
+      // == 0) are staged in the unused b1 slots [C, 3C) of the bias image; the positional table row of the panel's frame (the
+      // motion module's LayerNorm + PE) in [0, C) likewise.  Readers of the previous panel's copies are at least one of
+      // its QKV barriers behind. ----
+      const int64_t img = M0 / g.rows_per_img;
+      if (tid < 2 * C / 4) {
+        const __amdgpu_buffer_rsrc_t rAB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)const_cast<float*>(g.gn_ab + img * 2 * C), 0, 2 * C * 4, 0x00020000);
+        smem[BIAS_Q + (unsigned)(C / 4) + (unsigned)tid] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rAB, (unsigned)tid * 16u, 0, 0));
+      }
+    }
+    if constexpr (HEAD) {
+      if (g.ln_pe && tid < C / 4) {
+        const int64_t frame = (M0 / g.ln_rows_per_frame) % g.ln_pe_frames;
+        const __amdgpu_buffer_rsrc_t rPE = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)const_cast<float*>(g.ln_pe + frame * C), 0, C * 4, 0x00020000);
+        smem[BIAS_Q + (unsigned)tid] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rPE, (unsigned)tid * 16u, 0, 0));
+      }
+    }
+    if constexpr (MODE == 4) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const __amdgpu_buffer_rsrc_t rX4 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
+      const unsigned x4_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + lg * 8) * 4));
+      const unsigned x4_mi = (unsigned)(16 * g.ldx * 4);
+      const unsigned abq = pinned(BIAS_Q + (unsigned)(C / 4) + 2u * (unsigned)lg);
+      // four batches of 5 k-steps (10 loads of 16 B per lane), the next batch in flight while one is converted: all 40 loads
+      // at once would need 160 registers (the compiler hoists them and spills)
+      // (macros, not lambdas: arrays captured by reference two levels deep are not promoted to registers)
+      f32x4 xb0[KS], xb1[KS];
+#define FF_LOAD_BATCH(buf, mi, k0)                                                                                              \
+  _Pragma("unroll") for (int k = 0; k < KS / 2; ++k) {                                                                          \
+    buf[2 * k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128, (mi) * x4_mi, 0));          \
+    buf[2 * k + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128 + 16, (mi) * x4_mi, 0)); \
+  }                                                                                                                             \
+  __builtin_amdgcn_sched_barrier(0)
+#define FF_CONVERT_BATCH(buf, mi, k0)                                                                                           \
+  _Pragma("unroll") for (int k = 0; k < KS / 2; ++k) {                                                                          \
+    const f32x4 a0 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(8 * ((k0) + k))]);                                          \
+    const f32x4 a1 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(8 * ((k0) + k) + 1)]);                                      \
+    const f32x4 b0 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(C / 4 + 8 * ((k0) + k))]);                                  \
+    const f32x4 b1 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(C / 4 + 8 * ((k0) + k) + 1)]);                              \
+    const f32x4 y0 = __builtin_elementwise_fma(buf[2 * k], a0, b0), y1 = __builtin_elementwise_fma(buf[2 * k + 1], a1, b1);      \
+    uint32_t w0 = pack2<DT>(y0[0], y0[1]), w1 = pack2<DT>(y0[2], y0[3]), w2 = pack2<DT>(y1[0], y1[1]), w3 = pack2<DT>(y1[2], y1[3]); \
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); /* materialise HERE: the optimiser otherwise sinks the conversion to the first use and keeps x, a, b live */ \
+    fa[mi][(k0) + k] = make_uint4(w0, w1, w2, w3);                                                                              \
+  }                                                                                                                             \
+  __builtin_amdgcn_sched_barrier(0)
+      FF_LOAD_BATCH(xb0, 0, 0);
+      FF_LOAD_BATCH(xb1, 0, KS / 2);
+      FF_CONVERT_BATCH(xb0, 0, 0);
+      FF_LOAD_BATCH(xb0, 1, 0);
+      FF_CONVERT_BATCH(xb1, 0, KS / 2);
+      FF_LOAD_BATCH(xb1, 1, KS / 2);
+      FF_CONVERT_BATCH(xb0, 1, 0);
+      FF_CONVERT_BATCH(xb1, 1, KS / 2);
+#undef FF_LOAD_BATCH
+#undef FF_CONVERT_BATCH
+    } else if constexpr (MODE != 2) {
+      load_a();   // (MODE 2 loads it after the per-image vector: 80 registers fewer in flight)
+    }
     // ---- FF2 accumulators for columns [160 sh, 160 sh + 160): lane (li, lg) owns 4 consecutive columns of row li of each
     // 16-row tile.  MODE < 2: residual + b2.  MODE = 2: first the attention output projection accumulates on residual + bo
     // (+ the per-image vector), see below ----
@@ -245,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     const unsigned r_mi = (unsigned)(16 * g.ldr * 4);
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) {
-      const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((MODE == 2 ? 10 : 8) * C / 4 + 4 * nt)]);
+      const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((MODE >= 2 ? 10 : 8) * C / 4 + 4 * nt)]);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
         acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, 0)) + bv;
@@ -284,45 +361,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // both halves have read before the next round writes
       }
     };
-    if constexpr (MODE == 2) {
-      FF_TRACE(g, tr, 10);
-      if (g.img_bias) {
-        // the per-image vector (the collapsed cross-attention of the spatial blocks): the same 40 values per lane for every
-        // row of an image; rows_per_img >= 128, so a panel holds rows of at most two images
-        const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
-        const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
-        const int64_t img0 = M0 / g.rows_per_img;                                   // (scalar, once per panel)
-        const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);                  // panel row where the next image starts
-        const unsigned ib_off = (unsigned)((img0 * g.ldib + 160 * sh + 4 * lg) * 4);
-        if (next0 >= BM) {
-#pragma unroll
-          for (int nt = 0; nt < 10; ++nt) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, ib_off + nt * 64, 0, 0));
-            acc2[nt][0] += v;
-            acc2[nt][1] += v;
-          }
-        } else {
-          const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const unsigned o = ib_off + ((int)(pr * 32) + 16 * mi + li >= next0 ? step : 0u);
-#pragma unroll
-            for (int nt = 0; nt < 10; ++nt)
-              acc2[nt][mi] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + nt * 64, 0, 0));
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      load_a();
-      FF_TRACE(g, tr, 11);
-      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel); every tile: wait, barrier, issue the
-      // next position, multiply
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<0>{}); ++t; FF_TRACE(g, tr, 12);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<1>{}); ++t; FF_TRACE(g, tr, 13);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t; FF_TRACE(g, tr, 14);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t; FF_TRACE(g, tr, 15);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t; FF_TRACE(g, tr, 16);
+    // y (in acc2) -> n = LayerNorm(y) * gamma + beta (+ pe[frame]) as the next MFMA operand in fa (MODE 2: the feed-forward's,
+    // block head: the QKV projection's), straight from the accumulators
+    auto ln_operand = [&]() {
       // LayerNorm over the row's 320 columns: this wave holds 160 of them, 40 per lane.  Local sum and local centred sum of
       // squares, combined with the partner's by the pairwise update (mean = (s0 + s1) / 320, M2 = q0 + q1 + 80 (m0 - m1)^2);
       // both waves evaluate the combination with the halves in the same order: bit-identical statistics.
@@ -372,13 +413,116 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         for (int h = 0; h < 2; ++h) {
           const unsigned cq = (unsigned)(4 * (2 * kk + h));
           const f32x4 gm = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(11 * C / 4) + cq]);
-          const f32x4 bt = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(12 * C / 4) + cq]);
+          f32x4 bt = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(12 * C / 4) + cq]);
+          if constexpr (HEAD) bt += __builtin_bit_cast(f32x4, smem[bcol + cq]);  // + pe[frame] (zeros without a table)
           const f32x4 v = (acc2[2 * kk + h][mi] - mean[mi]) * rstd[mi] * gm + bt;
           w[2 * h] = pack2<DT>(v[0], v[1]);
           w[2 * h + 1] = pack2<DT>(v[2], v[3]);
         }
         return make_uint4(w[0], w[1], w[2], w[3]);
       });
+    };
+    if constexpr (HEAD) {
+      // ---- block head: y = (res +) A @ Wi^T + bi -> out32;  qkv = LayerNorm(y) @ Wqkv^T -> out (half, 3C columns) ----
+      FF_TRACE(g, tr, 10);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<0>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t;
+      FF_TRACE(g, tr, 16);
+      const int row0 = (int)pr * 32 + li;
+      {  // the fp32 stream leaves the chip once (the attention's residual)
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.out32 + M0 * g.ldo32), 0, (int)(((rows_valid - 1) * g.ldo32 + C) * 4), 0x00020000);
+        const unsigned o_off = pinned(((unsigned)row0 * (unsigned)g.ldo32 + 160u * sh + 4u * (unsigned)lg) * 4u);
+        const unsigned o_mi = 16u * (unsigned)g.ldo32 * 4u;
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rT, o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, 0);
+      }
+      ln_operand();
+      FF_TRACE(g, tr, 18);
+      // 15 tiles of Wqkv (natural row order: tile q = output columns 64 q .. 64 q + 63, this wave's n-tiles 2 sh, 2 sh + 1 =
+      // columns 64 q + 32 sh + [0, 32)); results leave as half in 16-byte stores (lane exchange of the paired epilogue)
+      const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + 3 * C) * 2), 0x00020000);
+      const unsigned q_off = pinned((((unsigned)row0 + 16u * (unsigned)(lg & 1)) * (unsigned)g.ldo + 32u * sh + 4u * (unsigned)(lg & ~1)) * 2u);
+#pragma unroll 1
+      for (int q = 0; q < NQKV; ++q) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_next();
+        const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+        f32x4 a1[2][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) a1[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a1[ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], a1[ni][mi]);
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x4 va = a1[ni][0], vb = a1[ni][1];
+          const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
+          const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rQ, q_off + 32u * (unsigned)ni, (unsigned)q * 128u, 0);
+        }
+        ++t;
+      }
+      FF_TRACE(g, tr, 22);
+      continue;
+    }
+    if constexpr (MODE == 2) {
+      FF_TRACE(g, tr, 10);
+      if (g.img_bias) {
+        // the per-image vector (the collapsed cross-attention of the spatial blocks): the same 40 values per lane for every
+        // row of an image; rows_per_img >= 128, so a panel holds rows of at most two images
+        const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
+        const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
+        const int64_t img0 = M0 / g.rows_per_img;                                   // (scalar, once per panel)
+        const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);                  // panel row where the next image starts
+        const unsigned ib_off = (unsigned)((img0 * g.ldib + 160 * sh + 4 * lg) * 4);
+        if (next0 >= BM) {
+#pragma unroll
+          for (int nt = 0; nt < 10; ++nt) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, ib_off + nt * 64, 0, 0));
+            acc2[nt][0] += v;
+            acc2[nt][1] += v;
+          }
+        } else {
+          const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const unsigned o = ib_off + ((int)(pr * 32) + 16 * mi + li >= next0 ? step : 0u);
+#pragma unroll
+            for (int nt = 0; nt < 10; ++nt)
+              acc2[nt][mi] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + nt * 64, 0, 0));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a();
+      FF_TRACE(g, tr, 11);
+      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel); every tile: wait, barrier, issue the
+      // next position, multiply
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<0>{}); ++t; FF_TRACE(g, tr, 12);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<1>{}); ++t; FF_TRACE(g, tr, 13);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<2>{}); ++t; FF_TRACE(g, tr, 14);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<3>{}); ++t; FF_TRACE(g, tr, 15);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue_next(); proj(ICf<4>{}); ++t; FF_TRACE(g, tr, 16);
+      ln_operand();
       FF_TRACE(g, tr, 18);
       // the feed-forward accumulates on y + b2
 #pragma unroll
@@ -586,7 +730,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int DT>
 static void ff_launch_dt(const FFArgs& g, int mode, unsigned grid, hipStream_t st) {
-  if (mode == 2) hipLaunchKernelGGL((ff_fused_kernel<DT, 2>), dim3(grid), dim3(512), 0, st, g);
+  if (mode == 4) hipLaunchKernelGGL((ff_fused_kernel<DT, 4>), dim3(grid), dim3(512), 0, st, g);
+  else if (mode == 3) hipLaunchKernelGGL((ff_fused_kernel<DT, 3>), dim3(grid), dim3(512), 0, st, g);
+  else if (mode == 2) hipLaunchKernelGGL((ff_fused_kernel<DT, 2>), dim3(grid), dim3(512), 0, st, g);
   else if (mode == 1) hipLaunchKernelGGL((ff_fused_kernel<DT, 1>), dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((ff_fused_kernel<DT, 0>), dim3(grid), dim3(512), 0, st, g);
 }
@@ -669,4 +815,29 @@ extern "C" int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, c
   g.bo = bo; g.img_bias = img_bias; g.ldib = ldib; g.rows_per_img = img_bias ? rows_per_img : 1;
   g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps;
   return ff_launch(dtype, g, 2, stream);
+}
+
+extern "C" int mimo_block_head_fused(int dtype, const void* A, int64_t lda, const float* x32, int64_t ldx, const float* gn_ab,
+                                     int64_t rows_per_img, const void* Wstream, const float* bi, const float* residual,
+                                     int64_t ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,
+                                     int64_t ln_rows_per_frame, int ln_pe_frames, float* y_out, int64_t ldy, void* qkv,
+                                     int64_t ldq, int64_t M, int C_, void* stream) {
+  if ((!A) == (!x32) || !Wstream || !ln_gamma || !ln_beta || !y_out || !qkv || M <= 0) return MIMO_EINVAL;
+  if (C_ != C) return MIMO_EINVAL;
+  if (x32 && (!gn_ab || rows_per_img < BM || (rows_per_img % BM) || (ldx & 3) || !aligned16(x32) || !aligned16(gn_ab))) return MIMO_EINVAL;
+  if (A && ((lda & 7) || !aligned16(A))) return MIMO_EINVAL;
+  if (residual && ((ldr & 3) || !aligned16(residual))) return MIMO_EINVAL;
+  if (ln_pe && (ln_rows_per_frame < BM || (ln_rows_per_frame % BM) || ln_pe_frames <= 0 || !aligned16(ln_pe))) return MIMO_EINVAL;
+  if ((ldy & 3) || (ldq & 7) || !aligned16(Wstream) || !aligned16(y_out) || !aligned16(qkv)) return MIMO_EINVAL;
+  if ((A && ((M - 1) * lda + C) * 2 >= 0x80000000LL) || (x32 && ((M - 1) * ldx + C) * 4 >= 0x100000000LL) ||
+      (residual && ((M - 1) * ldr + C) * 4 >= 0x100000000LL) || ((M - 1) * ldy + C) * 4 >= 0x100000000LL ||
+      ((M - 1) * ldq + 3 * C) * 2 >= 0x100000000LL)
+    return MIMO_EINVAL;
+  FFArgs g{};
+  g.A = (const uint16_t*)A; g.lda = lda; g.x = x32; g.ldx = ldx; g.gn_ab = gn_ab; g.rows_per_img = x32 ? rows_per_img : 1;
+  g.W1 = (const uint16_t*)Wstream; g.bo = bi; g.res = residual; g.ldr = ldr; g.M = M;
+  g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps;
+  g.ln_pe = ln_pe; g.ln_rows_per_frame = ln_pe ? ln_rows_per_frame : 1; g.ln_pe_frames = ln_pe ? ln_pe_frames : 1;
+  g.out32 = y_out; g.ldo32 = ldy; g.out = (uint16_t*)qkv; g.ldo = ldq;
+  return ff_launch(dtype, g, x32 ? 4 : 3, stream);
 }

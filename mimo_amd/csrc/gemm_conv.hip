@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   // staging role: thread -> row (tid >> 3) (+ 64 for the second DMA), physical chunk tid & 7 = logical chunk ^ (row & 7)
   const unsigned srow = (unsigned)tid >> 3, lc = ((unsigned)tid & 7u) ^ (srow & 7u);
   const unsigned av = srow * (unsigned)(g.lda * 2) + lc * 16u, bv = srow * (unsigned)(g.ldw * 2) + lc * 16u;
-  const unsigned a64 = (unsigned)(g.lda * 128), b64 = (unsigned)(g.ldw * 128);  // bytes of 64 rows
+  // The second DMA of a half-tile fetches row srow + 64.  Its 64-row stride rides in the LANE offset: only the vector
+  // offset is range checked against the clipped descriptor (the scalar offset is not), so a row beyond a ragged half-tile
+  // must be out of range in the voffset to be zero-filled instead of read past the end of A / W.
+  const unsigned av2 = av + (unsigned)(g.lda * 128), bv2 = bv + (unsigned)(g.ldw * 128);
   auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_base) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_base))
@@ -1149,7 +1152,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
     const unsigned soff = kt < nkt ? (unsigned)kt * 128u : 0u;
     const unsigned base = smem_base + (unsigned)(((d * 2 + o) * 2 + h) * HTB) + wave_u * 1024u;
     dma(r, o ? bv : av, soff, base);
-    dma(r, o ? bv : av, soff + (o ? b64 : a64), base + 8192u);
+    dma(r, o ? bv2 : av2, soff, base + 8192u);
   };
   // fragment bases: row li of a 16-row tile, chunk (4 kh + lg) ^ (li & 7); the wave's half-tile and column offset folded in
   unsigned ab[2][2], bb[2][2];

@@ -639,6 +639,8 @@ extern "C" int mimo_conv3x3_fused(int dtype, const float* x1, int C1, const floa
   // 32-bit offsets inside one image / one tile / the weight matrix; 2 GiB keeps OOBA + soffset out of range
   const int64_t src_px = (int64_t)g.Hs * g.Ws;
   const int64_t wb = (int64_t)g.N * ldw * 2;
+  // the source pixel index travels in 21 bits of pk[] (slot << 21) with Hs * Ws itself as the out-of-image sentinel
+  if (src_px >= (1LL << 21)) return MIMO_EINVAL;
   if (src_px * C1 * 4 >= 0x80000000LL || src_px * (int64_t)C2 * 4 >= 0x80000000LL || (int64_t)p->H * p->W * C * 2 >= 0x80000000LL ||
       wb >= 0x80000000LL || ((int64_t)15 * p->W + 16) * g.N * 4 >= 0x80000000LL)
     return MIMO_EINVAL;

@@ -70,6 +70,8 @@ SIGNATURES = {
                            c_vp],
     "mimo_block_tail_fused": [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp, c_vp],
+    "mimo_block_head_fused": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_i64, c_i,
+                              c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_vp],
     "mimo_temporal_attention": [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i64, c_i, c_i, c_f, c_vp],
     "mimo_softmax_rows": [c_i, c_vp, c_i64, c_vp, c_i64, c_i64, c_i, c_f, c_vp],
     "mimo_ncfhw_to_tokens": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_i64, c_i, c_vp, c_vp],

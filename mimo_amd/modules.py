@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import pack_block_tail_stream, pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
+from .packing import pack_block_head_stream, pack_block_tail_stream, pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
 
 
 LOG2E = 1.4426950408889634
@@ -333,6 +333,13 @@ def _ff_proj_run(ctx, p, y_f32, n3, proj, x_f32, colstats):
     return ops.gemm(z, proj["po_w"], bias=proj["po_b"], residual=x_f32, out_f32=True, colstats=colstats)
 
 
+def _head_fusable(ws, M, HW):
+    """mimo_block_head_fused applies: C = 320 (a packed stream exists), whole 128-row panels per image / frame, and the
+    row-count rule of the fused tails (a function of the layer and the frame size, never of the batch beyond the threshold)."""
+    return ops.BLOCK_HEAD_FUSED and ops.BLOCK_TAIL_FUSED and ops.FF_FUSED and ws is not None and HW % 128 == 0 and \
+        M <= ops.FF_FUSED_MAX_ROWS and (M >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled())
+
+
 def _block_tail_run(ctx, p, o, t, proj, x_f32, keys, ln_eps, img_bias=None, rows_per_img=1, colstats=False):
     """Everything after a block's attention core + the owning transformer's proj_out in one launch (C = 320), or None when
     the fused kernel does not apply.  keys = (to_out bias, LN gamma, LN beta) names in p; proj["tail_ws"] = the weight stream."""
@@ -368,9 +375,7 @@ class SpatialTransformerBlock(HipModule):
         a1 = self.attn1
         ff1_w, ff1_b = pack_geglu(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, dt)
         return dict(
-            # W_q carries softmax_scale * log2(e): the attention kernel then exponentiates the MFMA result as is
-            qkv=torch.cat([a1.to_q.weight.detach().float() * ((self.dim // self.heads) ** -0.5 * LOG2E),
-                           a1.to_k.weight.detach().float(), a1.to_v.weight.detach().float()], 0).to(dt).contiguous(),
+            qkv=self.qkv_weight().to(dt).contiguous(),
             kv=torch.cat([a1.to_k.weight, a1.to_v.weight], 0).detach().to(dt).contiguous(),
             o_w=a1.to_out[0].weight.detach().to(dt).contiguous(), o_b=_f32(a1.to_out[0].bias),
             ff1_w=ff1_w, ff1_b=ff1_b, ff2_w=self.ff.net[2].weight.detach().to(dt).contiguous(),
@@ -378,6 +383,12 @@ class SpatialTransformerBlock(HipModule):
             ff2_b=_f32(self.ff.net[2].bias),
             n1w=_f32(self.norm1.weight), n1b=_f32(self.norm1.bias),
             n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias))
+
+    def qkv_weight(self):
+        """fp32 [3C, C] = [W_q * softmax_scale * log2(e); W_k; W_v]: the attention kernel exponentiates the MFMA result as is."""
+        a1 = self.attn1
+        return torch.cat([a1.to_q.weight.detach().float() * ((self.dim // self.heads) ** -0.5 * LOG2E),
+                          a1.to_k.weight.detach().float(), a1.to_v.weight.detach().float()], 0)
 
     def attn2_matrix(self):
         """attn2 over ONE key collapses exactly: softmax == 1 -> out = to_out(to_v(e)) independent of the query
@@ -393,20 +404,25 @@ class SpatialTransformerBlock(HipModule):
         p = self.packed(dtype)
         return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps)
 
-    def run(self, ctx, t, n_img, N, out_f32=False, n1=None, proj=None, x=None):
-        """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it.
+    def run(self, ctx, t, n_img, N, out_f32=False, n1=None, proj=None, x=None, qkv=None):
+        """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it; qkv = the fused Q/K/V
+        projection of norm1(t) if the producer computed that too (mimo_block_head_fused; not in write mode, which banks n1).
         Returns the block output (half unless out_f32) — or, with proj = the owning transformer's packed proj_out and
         x = its fp32 input tokens, the transformer's output x + proj_out(block output) (fp32)."""
         p = self.packed(ctx.dtype)
         C = self.dim
-        if n1 is None:
-            n1 = ops.layer_norm(t, p["n1w"], p["n1b"], eps=self.norm1.eps, dtype=ctx.dtype)
-        if self.mode == "write":
-            bank = n1.view(n_img, N, C)
-            self.bank.append(bank if ctx.bank_rows is None else bank[ctx.bank_rows])
-            if ctx.stop_after is self:
-                raise EarlyExit()
-        qkv = ops.gemm(n1, p["qkv"]).view(n_img, N, 3 * C)
+        if qkv is None:
+            if n1 is None:
+                n1 = ops.layer_norm(t, p["n1w"], p["n1b"], eps=self.norm1.eps, dtype=ctx.dtype)
+            if self.mode == "write":
+                bank = n1.view(n_img, N, C)
+                self.bank.append(bank if ctx.bank_rows is None else bank[ctx.bank_rows])
+                if ctx.stop_after is self:
+                    raise EarlyExit()
+            qkv = ops.gemm(n1, p["qkv"])
+        else:
+            assert self.mode != "write"
+        qkv = qkv.view(n_img, N, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         if self.mode == "read" and self.bank_kv is not None:
             # rows [0, F) of a CFG batch are unconditional: self-attention only (mutual_self_attention.py:179-197)
@@ -462,6 +478,8 @@ class SpatialTransformer(HipModule):
                     tail_ws=pack_block_tail_stream(blk.attn1.to_out[0].weight,
                                                    pack_geglu(blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, dt)[0],
                                                    self.proj_out.weight.detach().reshape(C, -1), dt) if fusable else None,
+                    head_ws=pack_block_head_stream(self.proj_in.weight.detach().reshape(C, -1), blk.qkv_weight(), dt)
+                    if fusable and self.proj_in.in_channels == C else None,
                     pi_w=self.proj_in.weight.detach().reshape(C, -1).to(dt).contiguous(), pi_b=_f32(self.proj_in.bias),
                     po_w=self.proj_out.weight.detach().reshape(self.proj_out.out_channels, -1).to(dt).contiguous(),
                     po_b=_f32(self.proj_out.bias),
@@ -471,8 +489,17 @@ class SpatialTransformer(HipModule):
     def run(self, ctx, x):
         p = self.packed(ctx.dtype)
         n, H, W, C = x.shape
-        g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=1e-6, silu=False, dtype=ctx.dtype)
         blk = self.transformer_blocks[0]
+        if blk.mode != "write" and x.dtype == torch.float32 and _head_fusable(p["head_ws"], n * H * W, H * W):
+            # GroupNorm-apply + proj_in + norm1 + QKV in ONE launch (C = 320): the block is head, attention core, tail
+            stats = ops.group_norm_stats(x, groups=self.groups, eps=1e-6, dtype=ctx.dtype)
+            ab = ops.group_norm_affine(stats, p["g"], p["b"], C, groups=self.groups)
+            bp = blk.packed(ctx.dtype)
+            t, qkv = ops.block_head_fused(p["head_ws"], p["pi_b"], bp["n1w"], bp["n1b"], blk.norm1.eps, x=x.view(-1, C), gn_ab=ab,
+                                          rows_per_img=H * W)
+            out = blk.run(ctx, t, n, H * W, qkv=qkv, proj=p, x=x.view(-1, C))
+            return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
+        g, _ = ops.group_norm(x, p["g"], p["b"], groups=self.groups, eps=1e-6, silu=False, dtype=ctx.dtype)
         t, n1 = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=blk.ln1(ctx.dtype))
         out = blk.run(ctx, t, n, H * W, n1=n1, proj=p, x=x.view(-1, C))  # ... + proj_out + residual (one launch at C = 320)
         return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
@@ -542,6 +569,10 @@ class MotionModule(HipModule):
                  if self.dim == ops.FF_FUSED_DIM else None,
                  fnw=_f32(blk.ff_norm.weight), fnb=_f32(blk.ff_norm.bias))
         for i, (a, nrm) in enumerate(zip(blk.attention_blocks, blk.norms)):
+            qkv_w = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach()
+            # block head i: (GroupNorm + proj_in | the previous attention's to_out + residual) -> norms[i] + PE -> QKV
+            lead = tt.proj_in.weight if i == 0 else blk.attention_blocks[i - 1].to_out[0].weight
+            d[f"head_ws{i}"] = pack_block_head_stream(lead.detach(), qkv_w, dt) if self.dim == ops.FF_FUSED_DIM else None
             d[f"qkv{i}"] = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).detach().to(dt).contiguous()
             d[f"o_w{i}"], d[f"o_b{i}"] = h(a.to_out[0].weight), _f32(a.to_out[0].bias)
             d[f"nw{i}"], d[f"nb{i}"] = _f32(nrm.weight), _f32(nrm.bias)
@@ -554,11 +585,28 @@ class MotionModule(HipModule):
         HW = H * W
         if ctx.F > self.max_len:
             raise ValueError(f"window of {ctx.F} frames exceeds temporal_position_encoding_max_len={self.max_len}")
+        blk_eps = self.temporal_transformer.transformer_blocks[0].ff_norm.eps
+        if x.dtype == torch.float32 and _head_fusable(p["head_ws0"], n * HW, HW):
+            # C = 320: five launches — head (GroupNorm + proj_in + LN + PE + QKV), attention over frames, head (to_out +
+            # residual + LN + PE + QKV), attention, tail (to_out + residual + LN + feed-forward + proj_out + residual)
+            norms = self.temporal_transformer.transformer_blocks[0].norms
+            stats = ops.group_norm_stats(x, groups=32, eps=1e-6, dtype=ctx.dtype)
+            ab = ops.group_norm_affine(stats, p["g"], p["b"], C, groups=32)
+            t, qkv = ops.block_head_fused(p["head_ws0"], p["pi_b"], p["nw0"], p["nb0"], norms[0].eps, x=x.view(-1, C), gn_ab=ab,
+                                          rows_per_img=HW, pe=p["pe0"], rows_per_frame=HW, pe_frames=ctx.F)
+            o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
+            t, qkv = ops.block_head_fused(p["head_ws1"], p["o_b0"], p["nw1"], p["nb1"], norms[1].eps, a=o, residual=t,
+                                          pe=p["pe1"], rows_per_frame=HW, pe_frames=ctx.F)
+            o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
+            out = _block_tail_run(ctx, p, o, t, p, x.view(-1, C), ("o_b1", "fnw", "fnb"), blk_eps, colstats=HW)
+            if out is None:
+                t, u = ops.gemm(o, p["o_w1"], bias=p["o_b1"], residual=t, out_f32=True, ln=dict(gamma=p["fnw"], beta=p["fnb"]))
+                out = _ff_proj_run(ctx, p, t, u, p, x.view(-1, C), H * W)
+            return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=32, eps=1e-6, silu=False, dtype=ctx.dtype)
         # every LayerNorm (+ positional encoding) rides in the epilogue of the GEMM that produces its input
         ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], pe=p[f"pe{i}"], rows_per_frame=HW, pe_frames=ctx.F) for i in range(2)]
         ln.append(dict(gamma=p["fnw"], beta=p["fnb"]))
-        blk_eps = self.temporal_transformer.transformer_blocks[0].ff_norm.eps
         t, u = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=ln[0])
         out = None
         for i in range(2):

@@ -346,6 +346,43 @@ def block_tail_fused(o, wstream, bo, residual, ln_gamma, ln_beta, ln_eps, b1p, w
     return with_stats(out, cs)
 
 
+BLOCK_HEAD_FUSED = True   # everything BEFORE the attention core too: (GroupNorm ->) projection -> LayerNorm -> QKV (mimo_block_head_fused)
+
+
+def block_head_fused(wstream, bi, ln_gamma, ln_beta, ln_eps, *, a=None, x=None, gn_ab=None, rows_per_img=0, residual=None,
+                     pe=None, rows_per_frame=0, pe_frames=0):
+    """(y fp32 [M, C], qkv half [M, 3C]) in ONE launch (C = 320): y = (residual +) A' @ Wi^T + bi, qkv = (LayerNorm(y) (+ pe))
+    @ Wqkv^T with A' = `a` (half, an attention output) or half(x * ga + gb) — `x` the fp32 block input, gn_ab =
+    group_norm_affine(...) of the GroupNorm in front of proj_in.  wstream = packing.pack_block_head_stream(Wi, [Wq; Wk; Wv]).
+    Neither the normalised input nor the LayerNorm output reaches memory."""
+    src = a if a is not None else x
+    _chk(src, "a" if a is not None else "x")
+    assert (a is None) != (x is None)
+    M, C = src.shape
+    assert src.stride(1) == 1 and wstream.shape == (4 * C, C) and wstream.is_contiguous()
+    dtype = wstream.dtype
+    if a is not None:
+        assert a.dtype == dtype
+    else:
+        assert x.dtype == torch.float32 and gn_ab is not None and gn_ab.dtype == torch.float32 and gn_ab.is_contiguous()
+        assert gn_ab.shape == (M // rows_per_img, 2, C) and M % rows_per_img == 0 and rows_per_img % 128 == 0
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == (M, C) and residual.stride(1) == 1
+    if pe is not None:
+        assert pe.dtype == torch.float32 and pe.is_contiguous() and pe.shape[1] == C and pe.shape[0] >= pe_frames > 0
+        assert rows_per_frame % 128 == 0
+    y = torch.empty((M, C), device=src.device, dtype=torch.float32)
+    qkv = torch.empty((M, 3 * C), device=src.device, dtype=dtype)
+    fl = 2 * M * C * (C + 3 * C)
+    _count(fl)
+    with _Bracket("gemm_kernel", fl, _nbytes(src, wstream, residual, y, qkv), f"block_head_fused M{M}{' gn' if x is not None else ''}"):
+        L.call("mimo_block_head_fused", dt_code(dtype), _ptr(a), 0 if a is None else a.stride(0), _ptr(x), 0 if x is None else x.stride(0),
+               _ptr(gn_ab), int(rows_per_img), wstream.data_ptr(), _ptr(bi), _ptr(residual), 0 if residual is None else residual.stride(0),
+               ln_gamma.data_ptr(), ln_beta.data_ptr(), float(ln_eps), _ptr(pe), int(rows_per_frame), int(pe_frames),
+               y.data_ptr(), y.stride(0), qkv.data_ptr(), qkv.stride(0), M, C, _stream())
+    return y, qkv
+
+
 def conv2d(x, w, cout, *, ksize=3, stride=1, pad=None, out_hw=None, upsample_to=None, x2=None, bias=None,
            img_bias=None, imgs_per_bias_row=1, residual=None, out_f32=False, silu=False, out_scale=1.0, colstats=False,
            out=None):
@@ -501,8 +538,8 @@ def group_norm_affine(stats, gamma, beta, C, groups=32):
 # quantise worse than the row-tiled kernel's 192-row tiles (32 x 32 x 48 images x 640 channels = 384 blocks on 256 CUs).
 HCONV = True
 HCONV_MIN_HW = 4096
-HCONV_TILE_STATS = True
-HCONV_SLAB_STATS = True  # ... also with a residual (32-pixel slabs) and for the up-sampling convolution   # conv3x3_fused(tile_stats=True) also emits per-tile GroupNorm statistics of its output
+HCONV_TILE_STATS = True  # conv3x3_fused(tile_stats=True) also emits per-tile GroupNorm statistics of its output
+HCONV_SLAB_STATS = True  # ... also with a residual (32-pixel slabs) and for the up-sampling convolution
 
 
 def hconv_supported(x1, cout, *, x2=None, normed=True, upsample2x=False):

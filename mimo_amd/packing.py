@@ -103,3 +103,12 @@ def pack_block_tail_stream(to_out_w, ff1_w_packed, proj_out_w, dtype):
     order) | the GEGLU-packed FF1 weight (pack_geglu) with its K axis permuted — its operand, the LayerNorm output, comes
     straight from accumulator registers — | proj_out (pack_proj_tail)."""
     return torch.cat([pack_rows_tail(to_out_w, dtype), pack_ff2_kperm(ff1_w_packed, dtype), pack_proj_tail(proj_out_w, dtype)], 0).contiguous()
+
+
+def pack_block_head_stream(proj_w, qkv_w, dtype):
+    """The weight stream of mimo_block_head_fused, one [4 C, C] tensor in the order the kernel walks it: the leading projection
+    (proj_in | an attention's to_out; rows in tile order, K natural: its operand comes from memory) | the fused [Wq; Wk; Wv]
+    (natural row order = output column order, K axis permuted: its operand, the LayerNorm output, comes straight from
+    accumulator registers)."""
+    assert proj_w.shape[0] == proj_w.shape[1] and qkv_w.shape == (3 * proj_w.shape[0], proj_w.shape[1])
+    return torch.cat([pack_rows_tail(proj_w, dtype), pack_ff2_kperm(qkv_w, dtype)], 0).contiguous()

@@ -160,6 +160,12 @@ def _all_gather(send, world, group=None):
     """all_gather of equal-shape tensors.  RCCL (backend "nccl") takes device tensors as they are; the gloo backend
     (CPU tests, and the 2-ranks-on-one-GPU test) has no device all_gather, so device tensors are staged through the host."""
     import torch.distributed as dist
+    if dist.get_world_size(group) != world:
+        # emulation of ONE rank of a larger world on a single GPU (Pose2VideoPipeline.shard_emulate): the collective runs on
+        # the real (smaller) group — the backend's launch path is exercised — and the other ranks' chunks are stand-ins
+        recv = [torch.empty_like(send) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(recv, send.contiguous(), group=group)
+        return [recv[0]] * world
     if send.is_cuda and dist.get_backend(group) == "gloo":
         host = send.cpu()
         recv = [torch.empty_like(host) for _ in range(world)]
@@ -209,6 +215,13 @@ class UnitExchange:
 
     def _gather_slot(self, k):
         import torch.distributed as dist
+        if dist.get_world_size(self.group) != self.world:
+            # one rank of a larger world emulated on a single GPU: the slot is gathered on the real group (same call, same
+            # stream hand-over, 1 / world of the bytes); every other rank's entry is a copy of it (stand-in data)
+            self.works.append(dist.all_gather_into_tensor(self.recv[k, 0].view(-1), self.send[k].view(-1), group=self.group,
+                                                          async_op=True))
+            self.emulated = True
+            return
         if self.send.is_cuda and dist.get_backend(self.group) == "gloo":  # no device collectives in gloo: host staging
             host = self.send[k].reshape(-1).cpu()
             out = torch.empty((self.world * host.numel(),), dtype=host.dtype)
@@ -232,6 +245,8 @@ class UnitExchange:
             self.started += 1
         for w in self.works:
             w.wait()
+        if getattr(self, "emulated", False):
+            self.recv[:, 1:] = self.recv[:, :1]
         out = {u: self.recv[slot, r] for u, r, slot in self.assign}
         self.begin()
         return out
@@ -322,6 +337,8 @@ class Pose2VideoPipeline:
         self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
+        self.shard_emulate = None   # (rank, world): run THAT rank's share of a `world`-GPU sharded clip on this one GPU (needs a
+        #                             process group of size 1; other ranks' results are stand-ins: a timing mode, bench.py --emulate-rank)
         self.shard_force = False    # True: take the sharded code path (unit plan, per-slot async all_gather on the backend's
         #                             stream, item streams, sharded per-frame stages) even in a group of ONE rank — how the RCCL
         #                             branch is exercised on a single-GPU box (tests/test_models_gpu.py, bench.py --force-shard)
@@ -403,6 +420,8 @@ class Pose2VideoPipeline:
         world = 1
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.dist_group)
+            if self.shard_emulate is not None:
+                world = self.shard_emulate[1]
         with ops.split_k(not (world > 1 or self.batch_invariant or (self.shard_windows and self.shard_force))):
             return self._run_tensors(*args, **kwargs)
 
@@ -417,6 +436,10 @@ class Pose2VideoPipeline:
         if self.shard_windows and torch.distributed.is_available() and torch.distributed.is_initialized():
             import torch.distributed as dist
             rank, world = dist.get_rank(self.dist_group), dist.get_world_size(self.dist_group)
+            if self.shard_emulate is not None:
+                if world != 1:
+                    raise ValueError("shard_emulate runs on a process group of size 1")
+                rank, world = self.shard_emulate
         sharded = world > 1 or (self.shard_windows and self.shard_force and torch.distributed.is_available()
                                 and torch.distributed.is_initialized())
         sched.set_timesteps(num_inference_steps)

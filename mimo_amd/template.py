@@ -5,6 +5,7 @@ denoising path in run_edit.py.  Mirrors, with the reference
   pad_img                                                   tools/util.py:27-39
   init_bbox, bbox_div2, bbox_pad, compute_area_ratio        tools/util.py:111-160
   update_clip, crop_human_clip_auto_context                 tools/util.py:161-285
+  crop_human, init_bk                                       tools/util.py:71-110,339-344 (the animate entry: one box for the clip)
   prepare_clips      the per-frame padding loop of run_edit.py:226-248 (pose / background lists handed to the pipeline)
   clip_masks         get_mask + cv2.resize(mask, crop size, INTER_AREA) of run_edit.py:283-284, per generated frame
 
@@ -60,6 +61,28 @@ def crop_img_sdc(img, mask):
     x = max(0, x - int(w * pad_w))
     x_max = min(img.shape[1], x_max + int(w * pad_w))
     return y, y_max, x, x_max
+
+
+def crop_human(pose_images, vid_images, mask_images):
+    """tools/util.py:71-110: ONE bounding box of the subject over all pose frames (per-frame crop_img_sdc boxes united, an odd
+    side grown by one at its far edge — not re-clipped: a box at the image border stays odd after the slice, as in the
+    reference), applied to the pose, video and background frames alike.  -> three lists of PIL."""
+    y, y_max, x, x_max = 10000, 0, 10000, 0
+    for pose_img in pose_images:
+        frame = np.array(pose_img)
+        y_, y_max_, x_, x_max_ = crop_img_sdc(frame, extract_mask_sdc(frame))
+        y, y_max, x, x_max = min(y, y_), max(y_max, y_max_), min(x, x_), max(x_max, x_max_)
+    if (y_max - y) % 2 == 1:
+        y_max += 1
+    if (x_max - x) % 2 == 1:
+        x_max += 1
+    cut = lambda images: [Image.fromarray(np.array(im)[y:y_max, x:x_max]) for im in images]
+    return cut(pose_images), cut(vid_images), cut(mask_images)
+
+
+def init_bk(n_frame, h, w):
+    """tools/util.py:339-344: n white frames of h x w."""
+    return [Image.fromarray(np.ones((h, w, 3), dtype=np.uint8) * 255) for _ in range(n_frame)]
 
 
 def init_bbox():

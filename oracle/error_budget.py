@@ -12,7 +12,14 @@ once and should land near the product's measured figure.
 Classes:  W weights of every Linear / conv of both UNets | CONV inputs of the 3x3 convolutions (GroupNorm+SiLU outputs)
           LN inputs of to_q/to_k/to_v, FF1 and proj_in (LayerNorm / GroupNorm outputs) | QKV outputs of to_q/to_k/to_v
           ATT inputs of to_out (attention outputs) | H inputs of FF2 (GEGLU outputs) | Z inputs of proj_out (FF outputs)
-          P softmax probabilities before P.V"""
+          P softmax probabilities before P.V
+          RES (round 5) the residual stream itself: every tensor the product keeps in fp32 BETWEEN kernels (conv_in + pose,
+          conv1 + time embedding, ResBlock sums, proj_in outputs, every attention / feed-forward residual sum, proj_out + res,
+          sampler outputs) rounded to fp16 at every write, fp32 arithmetic inside.  Not part of 'all' (= the shipped policy);
+          'all+RES' is the policy the round-4 verdict asked to price.
+
+    python -m oracle.error_budget 4 RES            > profiles/r5_error_budget_res.txt     (configs[0], trajectory)
+    python -m oracle.error_budget forward512 RES   >> profiles/r5_error_budget_res.txt    (one configs[1]-shape forward)"""
 import sys
 import time
 
@@ -60,6 +67,115 @@ def hooks_for(cls, nets):
     return hs
 
 
+class RoundedStream:
+    """RES: swap the forwards of the oracle blocks for copies that round the residual stream at every write."""
+
+    def __enter__(self):
+        from einops import rearrange
+
+        R = q16
+        self.saved = [(c, c.forward) for c in (OM.ResnetBlock3D, OM.SpatialTransformerBlock, OM.Transformer3DModel,
+                                               OM.TemporalTransformerBlock, OM.TemporalTransformer3DModel,
+                                               OM.Upsample3D, OM.Downsample3D, OM.UNetBase)]
+        up_fwd, down_fwd, base_fwd = OM.Upsample3D.forward, OM.Downsample3D.forward, OM.UNetBase.forward
+
+        def resnet(self, x, temb):  # models.ResnetBlock3D.forward with the two stream writes rounded
+            h = self.conv1(F.silu(self.norm1(x)))
+            h = R(h + self.time_emb_proj(F.silu(temb))[:, :, None, None, None])
+            h = self.conv2(F.silu(self.norm2(h)))
+            if self.conv_shortcut is not None:
+                x = self.conv_shortcut(x)
+            return R((x + h) / self.output_scale_factor)
+
+        def spatial(self, x, encoder_hidden_states, video_length=1):
+            n = self.norm1(x)
+            if self.mode == "write":
+                self.bank.append(n.clone())
+                x = self.attn1(n) + x  # the product adds the collapsed attn2 in the same epilogue: ONE rounding below
+            elif self.mode == "read":
+                bank_fea = [rearrange(d.unsqueeze(1).repeat(1, video_length, 1, 1), "b t l c -> (b t) l c") for d in self.bank]
+                kv = torch.cat([n] + bank_fea, dim=1)
+                x_uc = self.attn1(n, encoder_hidden_states=kv) + x
+                if self.do_cfg:
+                    half = x.shape[0] // 2
+                    x_c = x_uc.clone()
+                    x_c[:half] = self.attn1(n[:half], encoder_hidden_states=n[:half]) + x[:half]
+                    x = x_c
+                else:
+                    x = x_uc
+            else:
+                x = self.attn1(n) + x
+            x = R(self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states) + x)
+            return R(self.ff(self.norm3(x)) + x)
+
+        def t3d(self, x, encoder_hidden_states):
+            f = x.shape[2]
+            x = rearrange(x, "b c f h w -> (b f) c h w")
+            if encoder_hidden_states.shape[0] != x.shape[0]:
+                encoder_hidden_states = encoder_hidden_states.repeat_interleave(f, dim=0)
+            b, c, h, w = x.shape
+            res = x
+            y = R(self.proj_in(self.norm(x)))
+            y = y.permute(0, 2, 3, 1).reshape(b, h * w, -1)
+            for blk in self.transformer_blocks:
+                y = blk(y, encoder_hidden_states, video_length=f)
+            y = y.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+            y = R(self.proj_out(y) + res)
+            return rearrange(y, "(b f) c h w -> b c f h w", f=f)
+
+        def tblock(self, x, video_length):
+            for attn, norm in zip(self.attention_blocks, self.norms):
+                x = R(attn(norm(x), video_length) + x)
+            return R(self.ff(self.ff_norm(x)) + x)
+
+        def tt3d(self, x):
+            f = x.shape[2]
+            x = rearrange(x, "b c f h w -> (b f) c h w")
+            b, c, h, w = x.shape
+            res = x
+            y = self.norm(x).permute(0, 2, 3, 1).reshape(b, h * w, c)
+            y = R(self.proj_in(y))
+            for blk in self.transformer_blocks:
+                y = blk(y, video_length=f)
+            y = self.proj_out(y).reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+            return rearrange(R(y + res), "(b f) c h w -> b c f h w", f=f)
+
+        def base(self, sample, timestep, encoder_hidden_states, pose_cond_fea=None):
+            hook = self.conv_in.register_forward_hook(
+                (lambda m, a, o: o) if pose_cond_fea is not None else (lambda m, a, o: R(o)))
+            pose_hook = None
+            if pose_cond_fea is not None:  # conv_in + pose is one epilogue in the product: round the sum
+                first = self.down_blocks[0].resnets[0]
+                pose_hook = first.register_forward_pre_hook(lambda m, a: (R(a[0]),) + tuple(a[1:]))
+                # the skip copy of the same tensor is the same stored tensor: round it too
+                orig = self.down_blocks[0].forward
+
+                def down0(x, temb, ehs):
+                    return orig(R(x), temb, ehs)
+
+                self.down_blocks[0].forward = down0
+            try:
+                return base_fwd(self, sample, timestep, encoder_hidden_states, pose_cond_fea)
+            finally:
+                hook.remove()
+                if pose_hook is not None:
+                    pose_hook.remove()
+                    del self.down_blocks[0].forward
+
+        OM.ResnetBlock3D.forward = resnet
+        OM.SpatialTransformerBlock.forward = spatial
+        OM.Transformer3DModel.forward = t3d
+        OM.TemporalTransformerBlock.forward = tblock
+        OM.TemporalTransformer3DModel.forward = tt3d
+        OM.Upsample3D.forward = lambda self, x, output_size=None: R(up_fwd(self, x, output_size))
+        OM.Downsample3D.forward = lambda self, x: R(down_fwd(self, x))
+        OM.UNetBase.forward = base
+
+    def __exit__(self, *a):
+        for c, f in self.saved:
+            c.forward = f
+
+
 class RoundedWeights:
     def __init__(self, nets):
         self.nets = nets
@@ -88,54 +204,86 @@ def sdpa_rounded_p(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False):
     return out
 
 
-def main(steps=4):
+ALL_CLASSES = ("CONV", "LN", "QKV", "ATT", "H", "Z")
+DEFAULT = ("W", "CONV", "LN", "QKV", "ATT", "H", "Z", "P", "all")
+
+
+def apply_class(cls, nets, run):
+    """Run `run()` with tensor class `cls` fake-quantised ('all' = the shipped policy, 'all+RES' = + fp16 residual stream)."""
+    hs, ctxs = [], []
+    everything = cls in ("all", "all+RES")
+    for c in (ALL_CLASSES if everything else (cls,)):
+        hs += hooks_for(c, nets)
+    if cls == "W" or everything:
+        ctxs.append(RoundedWeights(nets))
+    if cls in ("RES", "all+RES"):
+        ctxs.append(RoundedStream())
+    for c in ctxs:
+        c.__enter__()
+    if cls == "P" or everything:
+        OP.F.scaled_dot_product_attention = sdpa_rounded_p
+    try:
+        return run()
+    finally:
+        OP.F.scaled_dot_product_attention = _sdpa
+        for h_ in hs:
+            h_.remove()
+        for c in reversed(ctxs):
+            c.__exit__()
+
+
+def main(steps=4, classes=DEFAULT):
     torch.set_num_threads(8)
     t0 = time.time()
     o3 = synth.build(OM.UNet3DConditionModel, 1234, motion_heads=8, **OM.SD15_UNET_CONFIG)
     o2 = synth.build(OM.UNet2DConditionModel, 1235, **OM.SD15_UNET_CONFIG)
-    print(f"# full-size oracle UNets built in {time.time()-t0:.0f} s; BASELINE configs[0]: 256x256, 8 frames, {steps} DDIM steps, CFG 3.5", flush=True)
+    forward_only = steps == "forward512"
+    h, Fr = (64, 24) if forward_only else (32, 8)
+    what = ("ONE denoising forward at BASELINE configs[1] shape (512x512, 24 frames, CFG batch 2, bank from the reference UNet)"
+            if forward_only else f"BASELINE configs[0]: 256x256, 8 frames, {steps} DDIM steps, CFG 3.5")
+    print(f"# full-size oracle UNets built in {time.time()-t0:.0f} s; {what}", flush=True)
     g = torch.Generator().manual_seed(11)
-    h, Fr = 32, 8
     ehs = torch.randn(1, 1, 768, generator=g)
     ref_lat = torch.randn(1, 4, h, h, generator=g) * 0.8
     bk = torch.randn(1, 4, Fr, h, h, generator=g) * 0.8
     pose = torch.randn(1, 320, Fr, h, h, generator=g) * 0.5
     lat = torch.randn(1, 4, Fr, h, h, generator=g)
 
-    def run():
-        sched = OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
-        return denoise_clip(o2, o3, sched, ehs, ref_lat, bk, pose, lat.clone(), steps, 3.5, return_trajectory=True)[1]
+    if forward_only:
+        @torch.no_grad()
+        def run():
+            e2 = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+            writer = OM.ReferenceAttentionControl(o2, "write", do_classifier_free_guidance=True)
+            reader = OM.ReferenceAttentionControl(o3, "read", do_classifier_free_guidance=True)
+            o2(ref_lat.repeat(2, 1, 1, 1), torch.zeros((), dtype=torch.long), e2)
+            reader.update(writer)
+            x = torch.cat([lat, bk], dim=1).repeat(2, 1, 1, 1, 1)
+            out = o3(x, torch.tensor(951), e2, pose_cond_fea=pose.repeat(2, 1, 1, 1, 1))
+            reader.clear()
+            writer.clear()
+            return [out]
+        steps = 1
+    else:
+        def run():
+            sched = OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
+            return denoise_clip(o2, o3, sched, ehs, ref_lat, bk, pose, lat.clone(), steps, 3.5, return_trajectory=True)[1]
 
     base = run()
     print(f"# fp32 baseline done at {time.time()-t0:.0f} s", flush=True)
-    print(f"{'class':8s} " + " ".join(f"{'step ' + str(i):>10s}" for i in range(steps)))
+    print(f"{'class':8s} " + " ".join(f"{('noise_pred' if forward_only else 'step ' + str(i)):>10s}" for i in range(steps)))
     nets = (o3, o2)
     total_sq = [0.0] * steps
-    for cls in ("W", "CONV", "LN", "QKV", "ATT", "H", "Z", "P", "all"):
-        hs, ctx = [], None
-        classes = ("CONV", "LN", "QKV", "ATT", "H", "Z") if cls == "all" else (cls,)
-        for c in classes:
-            hs += hooks_for(c, nets)
-        if cls in ("W", "all"):
-            ctx = RoundedWeights(nets)
-            ctx.__enter__()
-        if cls in ("P", "all"):
-            OP.F.scaled_dot_product_attention = sdpa_rounded_p
-        try:
-            traj = run()
-        finally:
-            OP.F.scaled_dot_product_attention = _sdpa
-            for h_ in hs:
-                h_.remove()
-            if ctx is not None:
-                ctx.__exit__()
+    for cls in classes:
+        traj = apply_class(cls, nets, run)
         errs = [rel_l2(a, b) for a, b in zip(traj, base)]
-        if cls != "all":
+        if not cls.startswith("all"):
             total_sq = [t + e * e for t, e in zip(total_sq, errs)]
         print(f"{cls:8s} " + " ".join(f"{e:10.2e}" for e in errs), flush=True)
-    print(f"{'rss':8s} " + " ".join(f"{t ** 0.5:10.2e}" for t in total_sq) + "   (root of the summed squares of the single classes)")
+    print(f"{'rss':8s} " + " ".join(f"{t ** 0.5:10.2e}" for t in total_sq) + "   (root of the summed squares of the single classes listed)")
     print(f"# done in {time.time()-t0:.0f} s")
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
+    a = sys.argv[1:]
+    st = a[0] if a and a[0] == "forward512" else int(a[0]) if a else 4
+    main(st, tuple(a[1:]) or DEFAULT)

@@ -599,6 +599,58 @@ def test_template_functions_match_reference_tools_util():
     assert np.array_equal(T.crop_img(img, m), ns["crop_img"](img, m))
 
 
+@pytest.mark.reference
+def test_crop_human_matches_reference_tools_util():
+    """mimo_amd.template.crop_human / init_bk (the animate entry's ONE crop for the whole clip, run_animate.py:193-194) == the
+    reference's own tools/util.py:71-110,339-344 executed from source via `ast` (oracle/cv2_standin.py for the absent cv2):
+    same crops bit for bit on the pose, video and background frames; incl. a one-frame clip."""
+    import ast
+    import numpy as np
+    from PIL import Image
+    from mimo_amd import template as T
+    from oracle import cv2_standin
+    names = {"extract_mask_sdc", "crop_img_sdc", "crop_human", "init_bk"}
+    tree = ast.parse(open("/root/reference/tools/util.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in keep} == names
+    ns = {"np": np, "cv2": cv2_standin, "Image": Image}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "tools/util.py", "exec"), ns)
+    for seed, n in ((0, 40), (5, 17), (9, 1)):
+        pose, vid, bk = _synthetic_template(n=n, seed=seed)
+        ref = ns["crop_human"](pose, vid, bk)
+        out = T.crop_human(pose, vid, bk)
+        for a_list, b_list in zip(out, ref):
+            assert len(a_list) == len(b_list) == n
+            assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(a_list, b_list))
+        # (the reference grows an odd box by one at the far edge but does not re-check the image border: a box that touches the
+        # border stays odd after the slice — reproduced, not repaired)
+        w, h = out[0][0].size
+        assert all(im.size == (w, h) for lst in out for im in lst)
+    a, b = T.init_bk(3, 5, 7), ns["init_bk"](3, 5, 7)
+    assert len(a) == len(b) == 3 and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+def test_run_animate_frame_preparation():
+    """mimo_amd.run_animate.MIMO.prepare_frames (run_animate.py:170-206): frame-rate selection, frame cap, one crop for the clip,
+    pose padded black / background padded white to the same 16-multiple square."""
+    import numpy as np
+    from mimo_amd.run_animate import MIMO
+    pose, _, _ = _synthetic_template(n=20, seed=2)
+    m = MIMO(pipe=None, max_frame_num=7)
+    pl, bl = m.prepare_frames(pose, fps=60)            # 60 -> 30 fps keeps every second frame: 10, capped to 7
+    assert m.L == len(pl) == len(bl) == 7
+    # (320 x 240 driving frames: the reference's init_bk(n_frame, tw, th) call transposes the white frames, so their crop — and
+    # hence their padded square — may differ from the pose frames'; the pipeline resizes both to (width, height))
+    for lst in (pl, bl):
+        s = lst[0].size
+        assert s[0] == s[1] and s[0] % 16 == 0 and all(im.size == s for im in lst)
+    s = pl[0].size
+    assert all(int(np.asarray(b).min()) == 255 for b in bl)                       # white backgrounds, padded white
+    assert int(np.asarray(pl[0])[0, 0].sum()) == 0 or np.asarray(pose[0]).shape[0] == s[1]   # padded black
+    ref = MIMO.prepare_reference(np.full((50, 30, 3), 7, np.uint8))
+    assert ref.size == (64, 64) and int(np.asarray(ref)[0, 0, 0]) == 255 and int(np.asarray(ref)[32, 32, 0]) == 7
+
+
 def test_run_edit_frame_selection_known_answers():
     """run_edit.keep_frame_indices / time_crop_range: the codec-free arithmetic of load_video_fixed_fps
     (tools/util.py:462-479) and of the time crop (run_edit.py:194-198)."""

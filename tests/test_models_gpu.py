@@ -6,13 +6,14 @@ import os
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import north_star, rel_l2
 from helpers import MM4, build_pair_pose, build_pair_unets, build_pair_vae, small_kw
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float16, torch.bfloat16]
 # single-module tolerances; whole-model numbers are logged and asserted separately below
 TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+CFG_CAUSE = "CFG amplification u + 3.5 (c - u) on random-weight half-width models (profiles/r4_edge_case_bisect.txt)"
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
 
 
@@ -136,9 +137,11 @@ def test_vae_encode_decode(dev, dtype, H, W):
     out_d = pv.decode(z.to(dev)).sample.cpu()
     e1, e2 = rel_l2(out_m, ref_m), rel_l2(out_d, ref_d)
     report(f"vae {dtype} {H}x{W}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
-    # measured fp16: encode 1.5e-3, decode 2.2e-3 (x 1.3); bf16 scales with its 8x coarser mantissa
+    # measured fp16 (round 4): encode 1.47e-3 / 1.55e-3, decode 2.14e-3 / 2.01e-3; bf16 scales with its 8x coarser mantissa
     lim = {torch.float16: (2.0e-3, 2.9e-3), torch.bfloat16: (1.6e-2, 2.4e-2)}[dtype]
-    assert e1 < lim[0] and e2 < lim[1]
+    north_star(report, f"half-width VAE alone {H}x{W} {dtype} (not a denoised-latents figure)", {"encode": e1, "decode": e2},
+               {"encode": lim[0], "decode": lim[1]},
+               "16-bit MFMA operands: fp16 weight rounding alone is 1.3e-3 on sd-vae-ft-mse (profiles/r4_error_budget_vae.txt)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -234,8 +237,12 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
     report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W)
-    # CFG at guidance 3.5: 2e-3 (see test_pipeline_edge_cases_vs_oracle for the bound and the bisect); bf16 carries 8x the rounding
-    assert e_lat < {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype] and e_vid < {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype]
+    # CFG at guidance 3.5: regression guard 2e-3 (see test_pipeline_edge_cases_vs_oracle for the bound and the bisect; measured
+    # 1.44e-3 / 9.4e-4 in round 4); bf16 carries 8x the rounding (measured 1.11e-2 / 7.4e-3) and cannot meet 1e-3 at all
+    guard = {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype]
+    north_star(report, f"half-width models, F = 26, 2 steps, guidance 3.5, {dtype}", {"latents": e_lat, "video": e_vid}, guard,
+               "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt)" if dtype == torch.float16
+               else "bf16 operands: 8 mantissa bits (stated limit, DESIGN.md section 4)")
 
 
 @pytest.mark.parametrize("F,guidance,hw", [(1, 3.5, 64), (5, 1.0, 64), (24, 1.0, 40), (3, 3.5, 104)])
@@ -271,8 +278,12 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     # react to the CLIP embedding), i.e. up to sqrt(w^2 + (w - 1)^2) = 4.3x at w = 3.5 for independent errors — 2e-3.  The
     # bisect (profiles/r4_edge_case_bisect.txt: the same runs fed the ORACLE's VAE latents and pose features) shows the
     # 1.2-1.6e-3 of the CFG cases is this, not the VAE or the pose guider: exact inputs leave it unchanged, guidance 1 gives 6.8e-4.
-    bar = 1.0e-3 if guidance == 1.0 else 2.0e-3
-    assert e_lat < bar and e_vid < bar
+    # (round 4 measured: F=1 g=3.5 1.59e-3 / 1.10e-3; F=5 g=1 6.8e-4 / 6.3e-4; F=24 g=1 6.5e-4 / 6.1e-4; F=3 g=3.5 1.20e-3 / 7.4e-4)
+    if guidance == 1.0:
+        assert e_lat < 1.0e-3 and e_vid < 1.0e-3
+    else:
+        north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw}x{hw} fp16", {"latents": e_lat, "video": e_vid},
+                   2.0e-3, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
 
 
 def test_pipeline_rejects_what_the_reference_cannot_run(dev):
@@ -574,8 +585,65 @@ def test_run_edit_end_to_end_vs_oracle_chain(dev):
     report(f"run_edit MIMO.run end to end ({len(la['context_list'])} clips, {F} generated / {m.L} output frames, occluder, fp16): "
            f"video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, max |d|={int(d.max())}, "
            f"{100 * float((d > 1).mean()):.3f} % of values off by more than 1")
-    assert e_vid < 2e-3
     assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
+    north_star(report, "run_edit MIMO.run end to end, half-width models (decoded video, round 4: 7.5e-4)", {"video": e_vid}, 2e-3, CFG_CAUSE)
+
+
+def test_run_animate_end_to_end_vs_oracle_chain(dev):
+    """BASELINE configs[0]'s entry as ONE path: mimo_amd.run_animate.MIMO.run (run_animate.py:153-229: reference crop + pad,
+    30-fps selection of the driving frames, white backgrounds, ONE human-centred crop, per-frame padding,
+    Pose2VideoPipeline.__call__, uint8 frames by truncation) against the oracle chain on the same prepared inputs (the host-side
+    template functions are bit-exact vs the reference's own tools/util.py in test_host_cpu.py)."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig
+    from transformers import CLIPVisionModelWithProjection as RefCLIP
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.run_animate import MIMO
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    dtype = torch.float16
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=91)
+    ov, pv = build_pair_vae(dtype, dev, seed=92)
+    og, pg = build_pair_pose(dtype, dev, seed=93)
+    ccfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                            image_size=224, patch_size=32, projection_dim=768)
+    torch.manual_seed(6)
+    oclip = RefCLIP(ccfg).eval()
+    pclip = CLIPVisionModelWithProjection(ccfg)
+    pclip.load_state_dict({k: v for k, v in oclip.state_dict().items() if not k.endswith("position_ids")})
+    pclip.to(dev)
+    pclip.compute_dtype = dtype
+    pipe = Pose2VideoPipeline(vae=pv, image_encoder=pclip, reference_unet=p2, denoising_unet=p3, pose_guider=pg,
+                              scheduler=DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    pose, _, _, _ = _edit_template()
+    rs = np.random.RandomState(4)
+    ref_img = rs.randint(0, 256, (90, 70, 3), dtype=np.uint8)
+    ref_mask = np.zeros((90, 70), np.uint8)
+    ref_mask[10:80, 12:60] = 255
+    H = W = 64
+    m = MIMO(pipe, width=W, height=H, steps=2, cfg=3.5, seed=42, max_frame_num=8)
+    res, fps = m.run(ref_img, pose, fps=30, ref_mask=ref_mask)
+    la = m.last
+    F = len(la["pose_list"])
+    assert fps == 30 and len(res) == m.L == F == 8 and all(r.dtype == np.uint8 and r.shape == (H, W, 3) for r in res)
+    to_t = lambda im: torch.from_numpy(np.array(im.resize((W, H), Image.LANCZOS)).astype(np.float32) / 255.0).permute(2, 0, 1)
+    px = CLIPImageProcessor().preprocess(la["ref_image"].resize((224, 224)), return_tensors="pt").pixel_values
+    with torch.no_grad():
+        emb = oclip(pixel_values=px).image_embeds
+        lat = torch.randn((1, 4, F, H // 8, W // 8), generator=torch.manual_seed(42))
+        vid_o, _ = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), emb,
+                            (2 * to_t(la["ref_image"]) - 1)[None], torch.stack([2 * to_t(b) - 1 for b in la["bk_list"]]),
+                            torch.stack([to_t(p) for p in la["pose_list"]]), lat, 2, 3.5)
+    res_o = (vid_o[0].float().permute(1, 2, 3, 0).numpy() * 255).astype(np.uint8)   # run_animate.py:223-225
+    d = np.abs(np.stack(res).astype(np.int32) - res_o.astype(np.int32))
+    e_vid = rel_l2(la["video"].cpu(), vid_o[0])
+    report(f"run_animate MIMO.run end to end ({F} frames, fp16): video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, "
+           f"max |d|={int(d.max())}, {100 * float((d > 1).mean()):.3f} % of values off by more than 1")
+    assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
+    north_star(report, "run_animate MIMO.run end to end, half-width models (decoded video)", {"video": e_vid}, 2e-3, CFG_CAUSE)
 
 
 def test_pipeline_call_surface_pil_inputs(dev):
@@ -627,4 +695,5 @@ def test_pipeline_call_surface_pil_inputs(dev):
                             torch.stack([to_t(p) for p in poses]), lat, 2, 3.5)
     e = rel_l2(out, vid_o)
     report(f"pipeline __call__ (PIL inputs, HIP CLIP, per-frame backgrounds) fp16: video rel_l2={e:.2e}")
-    assert e < 2.0e-3  # CFG at guidance 3.5 on the half-width models: the bound of test_pipeline_edge_cases_vs_oracle
+    north_star(report, "Pose2VideoPipeline.__call__ with PIL inputs, half-width models (decoded video, round 4: 1.01e-3)", {"video": e}, 2.0e-3,
+               CFG_CAUSE)

@@ -114,6 +114,64 @@ def test_gemm_stream_k320(dev, dtype, M):
     assert out.shape == (M, inner) and rel_l2(out.float(), h[:, :inner] * F.gelu(h[:, inner:])) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256 * 26 + 64, 1280, 1280), (256 * 44 + 17, 960, 640), (48 * 9604 // 16, 1280, 640)])
+def test_gemm8_ragged_tiles_at_the_end_of_an_allocation(dev, dtype, M, N, K):
+    """The 8-phase kernel (gemm8_kernel: dense, K % 128 == 0, >= 128 tiles of 256 x 256) on ragged M (M % 128 = 64 is what
+    the reference's default 784 x 784 gives) and ragged N (960 = 3.75 tiles), with A and W ending exactly where their
+    allocation ends: a half-tile's second DMA must be clipped by the descriptor (zero fill), not read past the tensor.
+    Rows / columns of the ragged tiles are checked against fp32 separately (they are where a stale read would show)."""
+    from mimo_amd import ops
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 128
+    # one exact-size allocation each: the tensor's last byte is the allocation's last byte
+    a = torch.empty(M * K, device=dev, dtype=dtype).view(M, K).copy_(rnd((M, K), dev, dtype, 1))
+    w = torch.empty(N * K, device=dev, dtype=dtype).view(N, K).copy_(rnd((N, K), dev, dtype, 2, K ** -0.5))
+    bias = rnd((N,), dev, torch.float32, 3)
+    res = rnd((M, N), dev, torch.float32, 4)
+    ref = a.float() @ w.float().t() + bias
+    out = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+    assert rel_l2(out, ref + res) < ACC_TOL
+    m0, n0 = (M // 256) * 256, (N // 256) * 256
+    if m0 < M:
+        assert rel_l2(out[m0:], (ref + res)[m0:]) < ACC_TOL
+    if n0 < N:
+        assert rel_l2(out[:, n0:], (ref + res)[:, n0:]) < ACC_TOL
+    outh = ops.gemm(a, w, bias=bias)
+    assert outh.dtype == dtype and rel_l2(outh.float(), ref) < OUT_TOL[dtype]
+    assert bool(torch.isfinite(outh.float()).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_kernel_choice_is_batch_invariant_bit_for_bit(dev, dtype):
+    """The dense launcher picks gemm8_kernel by tile count (a function of M = rows of the BATCH) and the tiled kernel below
+    it.  A frame's bits must not depend on the batch it is computed in (sharded == single-GPU bit for bit), so the two
+    kernels must agree BIT FOR BIT: both accumulate K in the same order with the same MFMA and share one epilogue.
+    Computed here as: the whole batch (gemm8) vs its first quarter alone (tiled kernel), half / fp32 + residual / GEGLU /
+    ragged M."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_geglu
+    N, K = 1280, 1280
+    M = 256 * 26 + 64  # 135 tiles of 256 x 256 -> gemm8; a quarter of the rows is 35 tiles -> tiled kernel
+    Mq = 256 * 6 + 64
+    a = rnd((M, K), dev, dtype, 1)
+    w = rnd((N, K), dev, dtype, 2, K ** -0.5)
+    bias = rnd((N,), dev, torch.float32, 3)
+    res = rnd((M, N), dev, torch.float32, 4)
+    full = ops.gemm(a, w, bias=bias)
+    part = ops.gemm(a[:Mq].contiguous(), w, bias=bias)
+    assert torch.equal(full[:Mq], part)
+    full = ops.gemm(a, w, bias=bias, residual=res, out_f32=True)
+    part = ops.gemm(a[:Mq].contiguous(), w, bias=bias, residual=res[:Mq].contiguous(), out_f32=True)
+    assert torch.equal(full[:Mq], part)
+    inner = 2560
+    wg = rnd((2 * inner, K), dev, dtype, 5, K ** -0.5)
+    bg = rnd((2 * inner,), dev, torch.float32, 6, 0.1)
+    wp, bp = pack_geglu(wg, bg, dtype)
+    full = ops.gemm(a, wp, bias=bp, geglu=True)
+    part = ops.gemm(a[:256 * 3].contiguous(), wp, bias=bp, geglu=True)  # 3 x 20 = 60 tiles -> tiled GEGLU kernel
+    assert torch.equal(full[:256 * 3], part)
+
+
 CONV_CASES = [
     # n, H, W, Cin, Cout, ks, stride, pad(t,l), out_hw, upsample_to
     (2, 16, 16, 64, 160, 3, 1, None, None, None),
@@ -731,6 +789,80 @@ def test_block_tail_fused_c320(dev, dtype, M, rows_per_img):
         _check_tail_colstats(ops, lambda **kw: ops.block_tail_fused(o, ws, bo, t, gamma, beta, 1e-5, b1p, pack_ff2_kperm(w2, dtype), b2, bp, x,
                                                                     img_bias=ib, rows_per_img=rows_per_img or 1, **kw),
                              out, M, 128 if rows_per_img else 64, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,variant", [(1024, "gn"), (4096 * 3, "gn_pe"), (128, "a"), (8192 + 77, "a_res"), (33, "a_res"), (2048, "a_res_pe")])
+def test_block_head_fused_c320(dev, dtype, M, variant):
+    """mimo_block_head_fused (C = 320): (GroupNorm-apply +) projection (+ residual) -> y (fp32, written), LayerNorm (+ positional
+    table) -> QKV in one launch, vs a torch fp32 reference that rounds to half where the kernel does (the normalised input, the
+    LayerNorm output) and vs the three launches it replaces (GroupNorm-apply, GEMM + fused LayerNorm, QKV GEMM).
+    Variants: gn = fp32 block input + GroupNorm affine (the spatial transformer's head), gn_pe = + positional table (the motion
+    module's first head), a* = half operand (an attention output) with residual / table (its second head); ragged M."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_block_head_stream
+    C = 320
+    gn, res_on, pe_on = variant.startswith("gn"), "res" in variant, "pe" in variant
+    wi = rnd((C, C), dev, torch.float32, 10, C ** -0.5)
+    bi = rnd((C,), dev, torch.float32, 11, 0.1)
+    wqkv = rnd((3 * C, C), dev, torch.float32, 12, C ** -0.5)
+    gamma = 1 + rnd((C,), dev, torch.float32, 13, 0.2)
+    beta = rnd((C,), dev, torch.float32, 14, 0.2)
+    ws = pack_block_head_stream(wi, wqkv, dtype)
+    rpi = 512 if gn else 0                      # rows per image (GroupNorm affine) = rows per frame (positional table)
+    rpf, frames = (rpi or 256), 3
+    pe = rnd((5, C), dev, torch.float32, 15, 0.5) if pe_on else None
+    res = (rnd((M, C), dev, torch.float32, 16) + 0.5) if res_on else None
+    kw = dict(residual=res, pe=pe, rows_per_frame=rpf if pe_on else 0, pe_frames=frames if pe_on else 0)
+    if gn:
+        x = rnd((M, C), dev, torch.float32, 1, 2.0) + 0.3
+        ab = torch.stack([1 + rnd((M // rpi, C), dev, torch.float32, 2, 0.3), rnd((M // rpi, C), dev, torch.float32, 3, 0.3)], 1).contiguous()
+        y, qkv = ops.block_head_fused(ws, bi, gamma, beta, 1e-5, x=x, gn_ab=ab, rows_per_img=rpi, **kw)
+        img = torch.arange(M, device=dev) // rpi
+        a_ref = torch.addcmul(ab[img, 1], x, ab[img, 0]).to(dtype)   # fma, one rounding to half
+    else:
+        a_ref = rnd((M, C), dev, dtype, 1)
+        y, qkv = ops.block_head_fused(ws, bi, gamma, beta, 1e-5, a=a_ref, **kw)
+    assert y.shape == (M, C) and y.dtype == torch.float32 and qkv.shape == (M, 3 * C) and qkv.dtype == dtype
+    y_ref = a_ref.float() @ wi.to(dtype).float().t() + bi + (res if res_on else 0)
+    # (the GroupNorm variant's operand: torch.addcmul is not guaranteed to fuse; a half tie moved either way shows up at 1e-4)
+    assert rel_l2(y, y_ref) < (ACC_TOL if not gn else 3e-4)
+    n = F.layer_norm(y, (C,), gamma, beta, 1e-5)
+    if pe_on:
+        n = n + pe[(torch.arange(M, device=dev) // rpf) % frames]
+    q_ref = n.to(dtype).float() @ wqkv.to(dtype).float().t()
+    assert rel_l2(qkv.float(), q_ref) < OUT_TOL[dtype]
+    for sl in (slice(0, 1), slice(M - 1, M), slice(M // 2, M // 2 + 1)):
+        assert rel_l2(qkv[sl].float(), q_ref[sl]) < 2 * OUT_TOL[dtype]
+    for c in (0, 7, 319, 320, 639, 640, 959):
+        assert rel_l2(qkv[:, c].float(), q_ref[:, c]) < 2 * OUT_TOL[dtype]
+    # the launches it replaces
+    ln = dict(gamma=gamma, beta=beta, eps=1e-5)
+    if pe_on:
+        ln.update(pe=pe, rows_per_frame=rpf, pe_frames=frames)
+    y3, n3 = ops.gemm(a_ref, wi.to(dtype).contiguous(), bias=bi, residual=res, out_f32=True, ln=ln)
+    q3 = ops.gemm(n3, wqkv.to(dtype).contiguous())
+    assert rel_l2(y, y3) < (ACC_TOL if not gn else 3e-4) and rel_l2(qkv.float(), q3.float()) < OUT_TOL[dtype]
+
+
+def test_block_head_fused_is_batch_invariant(dev):
+    """A row's y / qkv bits depend on that row, its image's affine, its frame's table row and the weights only: a CFG half
+    (b = 1) alone equals the same rows of the b = 2 launch bit for bit."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_block_head_stream
+    dtype, C, rpi, F_ = torch.float16, 320, 1024, 3
+    M = 2 * F_ * rpi
+    ws = pack_block_head_stream(rnd((C, C), dev, torch.float32, 10, C ** -0.5), rnd((3 * C, C), dev, torch.float32, 12, C ** -0.5), dtype)
+    vec = [rnd((C,), dev, torch.float32, s, 0.1) for s in (11, 13, 14)]
+    x = rnd((M, C), dev, torch.float32, 1)
+    ab = rnd((M // rpi, 2, C), dev, torch.float32, 2)
+    pe = rnd((F_, C), dev, torch.float32, 3)
+    run = lambda sl, isl: ops.block_head_fused(ws, vec[0], 1 + vec[1], vec[2], 1e-5, x=x[sl], gn_ab=ab[isl].contiguous(), rows_per_img=rpi,
+                                               pe=pe, rows_per_frame=rpi, pe_frames=F_)
+    yf, qf = run(slice(0, M), slice(0, 2 * F_))
+    for h in range(2):
+        yh, qh = run(slice(h * F_ * rpi, (h + 1) * F_ * rpi), slice(h * F_, (h + 1) * F_))
+        assert torch.equal(yf[h * F_ * rpi:(h + 1) * F_ * rpi], yh) and torch.equal(qf[h * F_ * rpi:(h + 1) * F_ * rpi], qh)
 
 
 def test_block_tail_fused_is_batch_invariant(dev):

@@ -23,7 +23,14 @@ MFMA_RATE, HBM_RATE, ATTN_RATE = 1.3e15, 4.4e12, 1.0e15
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--mfma-rate", type=float, default=None, help="PFLOP/s to price the MFMA-bound launches at (default 1.3)")
+    ap.add_argument("--attn-rate", type=float, default=None, help="PFLOP/s to price spatial attention at (default 1.0)")
     a = ap.parse_args()
+    global MFMA_RATE, ATTN_RATE
+    if a.mfma_rate:
+        MFMA_RATE = a.mfma_rate * 1e15
+    if a.attn_rate:
+        ATTN_RATE = a.attn_rate * 1e15
     from mimo_amd import ops
     dev, dtype = torch.device("cuda:0"), torch.float16
     pipe = bench.build_pipeline(dev, dtype)

@@ -18,6 +18,11 @@
 #   hconv            tools/hconv_bench.py (old two-launch path vs fused conv)
 #   hconv_variants   tools/hconv_variants.py (needs `python tools/hconv_variants.py --build` before the gpurun call)
 #   vae_bound        tools/vae_bound.py --frames 8
+#   emulate8         bench.py --emulate-world 8 (per-rank schedule of the 8-GPU long-clip job measured on one GPU)
+#   ceiling          tools/ceiling.py (MFMA-only probe + best-case 8192^3 GEMMs)
+#   bound:<args>     tools/forward_bound.py --size 512 <args> (e.g. "bound:--mfma-rate 1.25 --attn-rate 1.0")
+#   head             tools/head_bench.py (fused block head vs the launches it replaces)
+#   ab:<settings>    tools/ab_forward.py <settings> (space-separated ops knobs, e.g. "ab:BLOCK_HEAD_FUSED=0 BLOCK_HEAD_FUSED=1")
 set -x
 TAG=$1; shift
 R=$PWD
@@ -53,6 +58,11 @@ for stage in "$@"; do
     bound) timeout 400 python tools/forward_bound.py --size 512 2>&1 | grep -v amdgpu.ids > $O/forward_bound_shapes_512.txt; head -30 $O/forward_bound_shapes_512.txt ;;
     hconv) timeout 400 python tools/hconv_bench.py 2>&1 | grep -v amdgpu.ids > $O/hconv_bench.txt; cat $O/hconv_bench.txt ;;
     hconv_variants) timeout 500 python tools/hconv_variants.py 2>&1 | grep -v amdgpu.ids > $O/hconv_variants.txt; cat $O/hconv_variants.txt ;;
+    emulate8) (timeout 600 python bench.py --emulate-world 8 > $O/bench_emulate_world8.json 2> $O/bench_emulate_world8.err); head -c 3000 $O/bench_emulate_world8.json ;;
+    ceiling) timeout 400 python tools/ceiling.py 2>&1 | grep -v amdgpu.ids > $O/mfma_ceiling.txt; cat $O/mfma_ceiling.txt ;;
+    bound:*) timeout 400 python tools/forward_bound.py --size 512 ${stage#bound:} 2>&1 | grep -v amdgpu.ids > $O/forward_bound_$n.txt; head -8 $O/forward_bound_$n.txt ;;
+    head) timeout 400 python tools/head_bench.py 2>&1 | grep -v amdgpu.ids > $O/head_bench.txt; cat $O/head_bench.txt ;;
+    ab:*) timeout 600 python tools/ab_forward.py ${stage#ab:} 2>&1 | grep -v amdgpu.ids > $O/ab_forward_$n.txt; cat $O/ab_forward_$n.txt ;;
     vae_bound) timeout 600 python tools/vae_bound.py --frames 8 2>&1 | grep -v amdgpu.ids > $O/vae_bound.txt; cat $O/vae_bound.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
