@@ -443,10 +443,17 @@ __device__ __forceinline__ int v_row_of_slot(int s) {
 // Two blocks share a CU, so each SIMD hosts two waves of DIFFERENT blocks whose phases drift: the hint lets the wave that
 // is entering an MFMA cluster win the issue arbitration against its partner's exp / pack VALU stream (cdna_hip_programming
 // T5; measured in profiles/r3_attn40_setprio_ab.txt).
-template <int DT, int NW, int ABL = 0, int STAGE = 0, int PRIO = 0>
-__global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
+// PIPE (round 5): software pipeline INSIDE the wave.  A wave issues in order: with the per-tile sequence Q.K^T MFMAs -> exp / pack
+// VALU -> P.V MFMAs the matrix pipe idles while the wave exponentiates, and the SIMD partner (a wave of the other resident
+// block) drifts into the same phase — measured MFMA-busy 0.48 = the serial sum 768 matrix + ~700 VALU cycles per wave and tile
+// (profiles/r5_attn40_isa_mix.txt, r5_mfma_ceiling.txt: v_exp_f32 6 cycles, other VALU 4 per wave64 instruction).  PIPE = 1
+// computes the scores of tile t + 1 while tile t is exponentiated: the Q.K^T MFMAs of t + 1 and the exp / pack of t are
+// independent and interleaved in program order (sched_group_barrier: one MFMA, then its share of the VALU work), P.V of query
+// block A runs under the last third of the exponentials; the ring is 4 deep (K of t + 1 is read one tile earlier).
+template <int DT, int NW, int ABL = 0, int STAGE = 0, int PRIO = 0, int PIPE = 0>
+__global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
-  constexpr int NB = 3;                     // ring depth (tiles t, t+1, t+2)
+  constexpr int NB = PIPE ? 4 : 3;          // ring depth (tiles t, t+1, t+2 [, t+3])
   constexpr int ROWB = 80;                  // K / V tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
   constexpr int TILEB = KV_TILE * ROWB;     // 5120 B per tile
   constexpr int K_OFF = 0, V_OFF = NB * TILEB;
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
   // Slow path of one query block (first tile, overshoot, ragged tile): recompute S, mask, move the reference to
   // ceil(running max) + HEAD, rescale O, redo exp + pack.  Exact softmax arithmetic; identical to the fast path's
   // result whenever the fast path is valid.
-  auto slow = [&](const uint4 (&kf)[2][3], int x, int t, int kv0, int nk, uint32_t (&w)[2][8]) {
+  auto slow = [&](const uint4 (&kf)[2][3], int x, int t, int kv0, int nk, uint32_t (&w)[2][8]) -> float {
     f32x16 st[2];
     qk(kf, x, st);
     if (kv0 + KV_TILE > nk) {
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k] - dlt), fast_exp2(st[u][2 * k + 1] - dlt));
+    return dlt;  // how far this lane's reference moved (PIPE: the scores of tile t + 1 were taken against the old one)
   };
   // packed P words of the 32x32 layout -> B operands of the 16x16x32 MFMA.  w[k] (k < 4) holds kv {0..3, 8..11} + 4 h2
   // and w[4 + k] kv {16..19, 24..27} + 4 h2 of query li.  Swapping the odd 16-lane rows of w[k] with the even rows of
@@ -799,6 +807,189 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     }
   };
 
+  // ---- PIPE = 1: one KV tile of the software-pipelined form.  S[P] holds the scores of tile t (computed one tile earlier),
+  // S[P ^ 1] receives those of tile t + 1 (MORE = false: t is the last tile).  CUR = t % 4 is the ring slot of tile t. ----
+  [[maybe_unused]] f32x16 S[2][2][2];  // [parity][query block x][kv sub-tile u]
+  auto load_kf = [&](int slot, uint4 (&kf)[2][3]) {
+    const unsigned char* kbuf = smem + slot * TILEB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB);
+      kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB + 32);
+      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + slot * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
+    }
+  };
+  // exp2 + pack of one 32 x 32 score sub-tile; returns the OR of the packed words
+  auto exp_pack_u = [&](const f32x16& st, uint32_t (&w)[8]) -> uint32_t {
+    uint32_t orr = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      w[k] = pack2<DT>(fast_exp2(st[2 * k]), fast_exp2(st[2 * k + 1]));
+      orr |= w[k];
+    }
+    return orr;
+  };
+  auto tile_p = [&](auto cur_c, auto par_c, auto more_c, int t) {
+    constexpr int CUR = decltype(cur_c)::value, P = decltype(par_c)::value;
+    constexpr bool MORE = decltype(more_c)::value != 0;
+    if (t + 3 < T) issue_tile(t + 3, (CUR + 3) % NB);  // slot (CUR + 3) % 4 held V of tile t - 1: last read before the previous barrier
+    const bool s2 = t >= T0;
+    const int nk = s2 ? a.Nk2 : a.Nk;
+    const int kv0 = (s2 ? t - T0 : t) * KV_TILE;
+    const bool special = (t == 0) | (kv0 + KV_TILE > nk);  // wave-uniform: first / ragged tiles take the slow path
+    // K fragments of tile t + 1, one kv half (u) at a time: 12 registers live instead of 24
+    uint4 kf[3];
+    auto load_ku = [&](int u) {
+      const unsigned char* kbuf = smem + ((CUR + 1) % NB) * TILEB;
+      kf[0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB);
+      kf[1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB + 32);
+      kf[2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + ((CUR + 1) % NB) * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
+    };
+    // Q.K^T of tile t + 1 for kv half u: two independent accumulator chains (query blocks A, B), interleaved
+    auto qk_u = [&](int u) {
+#pragma unroll
+      for (int sk = 0; sk < 3; ++sk)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+          S[P ^ 1][x][u] = HT<DT>::mfma32(kf[sk], qf[x][sk], sk == 0 ? zero16 : S[P ^ 1][x][u]);
+    };
+    uint32_t wa[2][8], wb[2][8];
+    uint4 pa[2][2], pb[2][2];
+    uint2 vlo[3][2], vhi[3][2];
+    // ---- phase B1: Q.K^T of tile t + 1, kv half 0 (6 MFMAs of 32 matrix-pipe cycles) under the exponentials of query block A
+    // (64 VALU instructions) ----
+    if constexpr (MORE) {
+      load_ku(0);
+      qk_u(0);
+    }
+    uint32_t ora = exp_pack_u(S[P][0][0], wa[0]);
+    ora |= exp_pack_u(S[P][0][1], wa[1]);
+    if constexpr (MORE) {
+      // (one MFMA, then its share of the exp / pack / or stream: 64 VALU instructions over 6 MFMAs)
+#define MIMO_SGB(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+      MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(10); MIMO_SGB(10);
+#undef MIMO_SGB
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B2: kv half 1 under the exponentials of query block B; the V^T fragments of tile t are requested here (12
+    // transposed reads, waited for before P.V; the compiler does not track asm loads: the wait statement names them) ----
+    if constexpr (MORE) {
+      load_ku(1);
+      qk_u(1);
+    }
+    {
+      const unsigned va2 = vaddr2 + (unsigned)(CUR * TILEB) * vstep2;
+#define MIMO_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        MIMO_TR(vlo[0][u], vaddr, CUR * TILEB + 32 * u * ROWB);
+        MIMO_TR(vhi[0][u], vaddr, CUR * TILEB + (32 * u + HI) * ROWB);
+        MIMO_TR(vlo[1][u], vaddr, CUR * TILEB + 32 * u * ROWB + 32);
+        MIMO_TR(vhi[1][u], vaddr, CUR * TILEB + (32 * u + HI) * ROWB + 32);
+      }
+      {
+        const unsigned a00 = va2, a01 = va2 + (HI * ROWB) * vstep2, a10 = va2 + (32 * ROWB) * vstep2, a11 = va2 + ((32 + HI) * ROWB) * vstep2;
+        MIMO_TR(vlo[2][0], a00, 0);
+        MIMO_TR(vhi[2][0], a01, 0);
+        MIMO_TR(vlo[2][1], a10, 0);
+        MIMO_TR(vhi[2][1], a11, 0);
+      }
+#undef MIMO_TR
+    }
+    uint32_t orb = exp_pack_u(S[P][1][0], wb[0]);
+    orb |= exp_pack_u(S[P][1][1], wb[1]);
+    if constexpr (MORE) {
+      // (one MFMA, then its share of the exp / pack / or stream: 64 VALU instructions over 6 MFMAs)
+#define MIMO_SGB(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x002, n, 1)
+      MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(10); MIMO_SGB(10);
+#undef MIMO_SGB
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float dlt_a = 0.f, dlt_b = 0.f;
+    if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) {
+      uint4 kc[2][3];
+      load_kf(CUR, kc);
+      dlt_a = slow(kc, 0, t, kv0, nk, wa);
+    }
+    if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) {
+      uint4 kc[2][3];
+      load_kf(CUR, kc);
+      dlt_b = slow(kc, 1, t, kv0, nk, wb);
+    }
+    to_frag(wa, pa);
+    to_frag(wb, pb);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vlo[2][0]), "+v"(vlo[2][1]),
+                   "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1]), "+v"(vhi[2][0]), "+v"(vhi[2][1])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // no MFMA may be hoisted above the wait
+    // ---- phase E: O^T += V^T.P^T, 24 MFMAs of 16 matrix-pipe cycles; every V^T fragment feeds 4 query tiles ----
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 vf = make_uint4(vlo[dt][u].x, vlo[dt][u].y, vhi[dt][u].x, vhi[dt][u].y);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          ot[0][dt][j] = HT<DT>::mfma16(vf, pa[u][j], ot[0][dt][j]);
+          ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
+        }
+      }
+    if constexpr (MORE) {
+      // the scores of tile t + 1 were taken against the reference a slow path may just have moved (rare: wave-uniform skip)
+      if (__builtin_amdgcn_ballot_w64((dlt_a != 0.f) | (dlt_b != 0.f)) != 0ull) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            S[P ^ 1][0][u][r] -= dlt_a;
+            S[P ^ 1][1][u][r] -= dlt_b;
+          }
+      }
+      // tile t + 2 (issued two iterations ago) has to be in LDS for the next iteration's Q.K^T; tile t + 3 may stay in flight
+      if (t + 3 < T) wait_all_but_newest();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // publishes the staged tiles; every wave is done reading K of slot CUR + 1 and V of slot CUR
+    }
+  };
+
+  if constexpr (PIPE != 0) {
+    issue_tile(0, 0);
+    if (T > 1) issue_tile(1, 1);
+    if (T > 2) issue_tile(2, 2);
+    if (T > 2) wait_all_but_newest();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tiles 0 and 1 and the constant slots are visible
+    {
+      uint4 kf[2][3];
+      load_kf(0, kf);
+      qk(kf, 0, S[0][0]);
+      qk(kf, 1, S[0][1]);
+    }
+    int t = 0;
+    for (; t + 4 < T; t += 4) {
+      tile_p(IC2<0>{}, IC2<0>{}, IC2<1>{}, t);
+      tile_p(IC2<1>{}, IC2<1>{}, IC2<1>{}, t + 1);
+      tile_p(IC2<2>{}, IC2<0>{}, IC2<1>{}, t + 2);
+      tile_p(IC2<3>{}, IC2<1>{}, IC2<1>{}, t + 3);
+    }
+    const int rem = T - t;  // 1..4 tiles left (t is a multiple of 4: slot 0, parity 0)
+    if (rem == 1) {
+      tile_p(IC2<0>{}, IC2<0>{}, IC2<0>{}, t);
+    } else if (rem == 2) {
+      tile_p(IC2<0>{}, IC2<0>{}, IC2<1>{}, t);
+      tile_p(IC2<1>{}, IC2<1>{}, IC2<0>{}, t + 1);
+    } else if (rem == 3) {
+      tile_p(IC2<0>{}, IC2<0>{}, IC2<1>{}, t);
+      tile_p(IC2<1>{}, IC2<1>{}, IC2<1>{}, t + 1);
+      tile_p(IC2<2>{}, IC2<0>{}, IC2<0>{}, t + 2);
+    } else {
+      tile_p(IC2<0>{}, IC2<0>{}, IC2<1>{}, t);
+      tile_p(IC2<1>{}, IC2<1>{}, IC2<1>{}, t + 1);
+      tile_p(IC2<2>{}, IC2<0>{}, IC2<1>{}, t + 2);
+      tile_p(IC2<3>{}, IC2<1>{}, IC2<0>{}, t + 3);
+    }
+  } else {
   // ---- pipeline: two tiles in flight ahead of the one being consumed; ONE barrier per tile ----
   if (STAGE == 1) {
     stage_loads(0);
@@ -820,6 +1011,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn40_kernel(const AttnArgs a) {
     if (t + 1 < T) tile(IC2<1>{}, t + 1);
     if (t + 2 < T) tile(IC2<2>{}, t + 2);
   }
+  }  // PIPE == 0
 
   // ---- epilogue: denominators from the ones-row (d = 40: tile 2, row 8 -> lane group 2, register 0) ----
 #pragma unroll
@@ -1362,6 +1554,15 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   }
   if (nw == 8) {
     hipLaunchKernelGGL((attn40_kernel<DT, 8, 0>), grid, dim3(512), 0, st, a);
+    return;
+  }
+#endif
+#ifdef MIMO_TUNE
+  // round-5 experiment (profiles/r5_attn40_pipe_ab.txt): the software-pipelined tile.  PIPE = 2 (one wave per SIMD, 512
+  // registers) is correct and exactly as fast as the shipped form; PIPE = 1 (two waves per SIMD) does not fit 256 registers —
+  // its scratch traffic breaks the counted vmcnt waits (wrong results) — and is not instantiated.
+  if (tune_env("MIMO_ATTN40_PIPE", 0) == 2) {
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0, 2>), grid, dim3(256), 0, st, a);
     return;
   }
 #endif

@@ -450,26 +450,38 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + 3 * C) * 2), 0x00020000);
       const unsigned q_off = pinned((((unsigned)row0 + 16u * (unsigned)(lg & 1)) * (unsigned)g.ldo + 32u * sh + 4u * (unsigned)(lg & ~1)) * 2u);
-#pragma unroll 1
-      for (int q = 0; q < NQKV; ++q) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // One QKV tile.  The wait is COUNTED: vmcnt is one in-order counter for loads and stores, and a vmcnt(0) here would
+      // also wait for the acknowledgement of the previous step's output stores (a memory round trip per step).  NEWER =
+      // the number of this wave's vector-memory instructions issued after the DMAs of the tile about to be read: 20 y stores
+      // before the first tile, 2 qkv stores afterwards (the waves of column half 0 issue no DMAs: they wait for nothing).
+      auto qkv_step = [&](int q, auto newer_c) {
+        constexpr int NEWER = decltype(newer_c)::value;
+        FF_TRACE(g, tr, 1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEWER) : "memory");
+        FF_TRACE(g, tr, 2);
+        asm volatile("s_barrier" ::: "memory");
+        FF_TRACE(g, tr, 3);
         issue_next();
+        FF_TRACE(g, tr, 4);
         const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
         f32x4 a1[2][2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) a1[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!FF_ABLATE(g, 2)) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+          for (int ks = 0; ks < KS; ++ks) {
+            const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
+            for (int ni = 0; ni < 2; ++ni) {
+              const uint4 wf = smem[qq + (2u * sh + (unsigned)ni) * 128u];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a1[ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], a1[ni][mi]);
+              for (int mi = 0; mi < 2; ++mi) a1[ni][mi] = HT<DT>::mfma16(wf, fa[mi][ks], a1[ni][mi]);
+            }
           }
         }
+        FF_TRACE(g, tr, 5);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const f32x4 va = a1[ni][0], vb = a1[ni][1];
@@ -479,7 +491,11 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
           __builtin_amdgcn_raw_buffer_store_b128(o, rQ, q_off + 32u * (unsigned)ni, (unsigned)q * 128u, 0);
         }
         ++t;
-      }
+        FF_TRACE(g, tr, 6);
+      };
+      qkv_step(0, ICf<20>{});
+#pragma unroll 1
+      for (int q = 1; q < NQKV; ++q) qkv_step(q, ICf<2>{});
       FF_TRACE(g, tr, 22);
       continue;
     }

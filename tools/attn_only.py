@@ -24,7 +24,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 if "--time" in sys.argv:  # A/B of an environment knob read per launch: python tools/attn_only.py --time MIMO_ATTN_KT32
     knob = sys.argv[sys.argv.index("--time") + 1]
-    for env in ("0", "1", "0", "1"):
+    i = sys.argv.index("--time") + 2
+    vals = sys.argv[i].split(",") if len(sys.argv) > i and not sys.argv[i].startswith("--") else ["0", "1"]
+    ref = None
+    for env in vals + vals:
         os.environ[knob] = env
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         run()
@@ -33,7 +36,10 @@ if "--time" in sys.argv:  # A/B of an environment knob read per launch: python t
             o = run()
         en.record()
         torch.cuda.synchronize()
-        print(f"{knob}={env}: {st.elapsed_time(en)/10:.3f} ms  checksum {float(o.float().abs().mean()):.6f}", flush=True)
+        if ref is None:
+            ref = o.float().clone()
+        print(f"{knob}={env}: {st.elapsed_time(en)/10:.3f} ms  checksum {float(o.float().abs().mean()):.6f}  "
+              f"rel-L2 vs the first variant {float((o.float() - ref).norm() / ref.norm()):.2e}", flush=True)
 import threading
 t = threading.Timer(30.0, os._exit, [0])
 t.daemon = True

@@ -1,7 +1,9 @@
 """Phase trace and ablations of ff_fused_kernel (tune build): threads 0 (wave 0: column half 0) and 256 (wave 4: column half 1,
 the DMA issuer) of block 0 stamp the cycle counter around every phase of a steady-state step; the ablations time the launch
 without DMAs (stale tiles: compute only), without the MFMA phases (stream + barriers only) and with GELU -> identity.
-    python tools/ff_trace.py [mode ...]      mode: 1 = mimo_ff_proj_fused, 2 = mimo_block_tail_fused"""
+    python tools/ff_trace.py [mode ...]      mode: 1 = mimo_ff_proj_fused, 2 = mimo_block_tail_fused,
+                                             3 / 4 = mimo_block_head_fused on a half operand + residual + table / on the fp32 input
+                                             (steady-state step = one QKV tile: "ff2" column = its 40 MFMAs, "ff1" = the two stores)"""
 import ctypes
 import os
 import sys
@@ -16,7 +18,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from mimo_amd import lib as L, ops  # noqa: E402
-from mimo_amd.packing import pack_block_tail_stream, pack_ff2_kperm, pack_geglu, pack_proj_tail  # noqa: E402
+from mimo_amd.packing import pack_block_head_stream, pack_block_tail_stream, pack_ff2_kperm, pack_geglu, pack_proj_tail  # noqa: E402
 
 NAMES = {(1, 2): "vmwait", (2, 3): "barrier", (3, 4): "dma_issue", (4, 5): "ff2", (5, 6): "ff1", (6, 1): "loop"}
 
@@ -69,7 +71,8 @@ def report(name, fn):
     # the panel's prologue (block_tail_fused) and tail: cycles between consecutive stamps, averaged over the block's panels
     PRO = {(10, 11): "loads issued", (11, 12): "Wo tile 0", (12, 13): "Wo tile 1", (13, 14): "Wo tile 2", (14, 15): "Wo tile 3",
            (15, 16): "Wo tile 4", (16, 17): "LN statistics", (17, 18): "operand exchange", (18, 19): "first FF step",
-           (6, 20): "drain wait", (19, 20): "drain wait", (20, 21): "drain FF2 + exchange", (21, 22): "x load + 5 Wp tiles"}
+           (6, 20): "drain wait", (19, 20): "drain wait", (20, 21): "drain FF2 + exchange", (21, 22): "x load + 5 Wp tiles",
+           (10, 16): "operand load + 5 projection tiles", (16, 18): "y store + LN + operand exchange", (6, 22): "(end of panel)"}
     for who, sl in (("wave 0", a[:2000]), ("wave 4", a[2000:4000])):
         ev = [(int(v >> np.uint64(56)), int(v & np.uint64((1 << 56) - 1))) for v in sl if v]
         acc, cnt = {}, {}
@@ -105,6 +108,16 @@ def main(modes):
         print(f"the to_out + LayerNorm launch it absorbs: {timed(base):.3f} ms", flush=True)
         pair = lambda: (base(), ops.ff_proj_fused(a, w1p, b1p, w2k, b2, res, wpk, bp, x))
         print(f"to_out + LayerNorm launch followed by ff_proj_fused: {timed(pair):.3f} ms", flush=True)
+    if 3 in modes or 4 in modes:
+        wh = pack_block_head_stream(wo, r(3 * C, C, sc=C ** -0.5), dt)
+        pe = r(24, C, sc=0.5)
+        if 3 in modes:
+            report("block_head_fused (half operand + residual + table)",
+                   lambda: ops.block_head_fused(wh, bo, gm, bt, 1e-5, a=a, residual=res, pe=pe, rows_per_frame=4096, pe_frames=24))
+        if 4 in modes:
+            ab = r(48, 2, C)
+            report("block_head_fused (fp32 input + GroupNorm affine)",
+                   lambda: ops.block_head_fused(wh, bo, gm, bt, 1e-5, x=x, gn_ab=ab, rows_per_img=4096))
 
 
 if __name__ == "__main__":

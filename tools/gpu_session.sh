@@ -18,6 +18,8 @@
 #   hconv            tools/hconv_bench.py (old two-launch path vs fused conv)
 #   hconv_variants   tools/hconv_variants.py (needs `python tools/hconv_variants.py --build` before the gpurun call)
 #   vae_bound        tools/vae_bound.py --frames 8
+#   attn_ab:<KNOB> <v0,v1,..>   tools/attn_only.py --time (level-0 spatial attention under a tune-library knob)
+#   envtests:<ENV=..>;<expr>    pytest -k <expr> on the tune library with environment knobs set
 #   emulate8         bench.py --emulate-world 8 (per-rank schedule of the 8-GPU long-clip job measured on one GPU)
 #   ceiling          tools/ceiling.py (MFMA-only probe + best-case 8192^3 GEMMs)
 #   bound:<args>     tools/forward_bound.py --size 512 <args> (e.g. "bound:--mfma-rate 1.25 --attn-rate 1.0")
@@ -58,9 +60,12 @@ for stage in "$@"; do
     bound) timeout 400 python tools/forward_bound.py --size 512 2>&1 | grep -v amdgpu.ids > $O/forward_bound_shapes_512.txt; head -30 $O/forward_bound_shapes_512.txt ;;
     hconv) timeout 400 python tools/hconv_bench.py 2>&1 | grep -v amdgpu.ids > $O/hconv_bench.txt; cat $O/hconv_bench.txt ;;
     hconv_variants) timeout 500 python tools/hconv_variants.py 2>&1 | grep -v amdgpu.ids > $O/hconv_variants.txt; cat $O/hconv_variants.txt ;;
+    attn_ab:*) timeout 300 python tools/attn_only.py --time ${stage#attn_ab:} 2>&1 | grep -v amdgpu.ids > $O/attn_ab_$n.txt; cat $O/attn_ab_$n.txt ;;
+    envtests:*) (IFS=';' read -r ENVS EXPR <<< "${stage#envtests:}"; env MIMO_HIP_LIB=$R/mimo_amd/libmimo_hip_tune.so $ENVS timeout 900 python -m pytest tests -m gpu -q -k "$EXPR" 2>&1 | tail -8) > $O/pytest_env_$n.txt; tail -3 $O/pytest_env_$n.txt ;;
     emulate8) (timeout 600 python bench.py --emulate-world 8 > $O/bench_emulate_world8.json 2> $O/bench_emulate_world8.err); head -c 3000 $O/bench_emulate_world8.json ;;
     ceiling) timeout 400 python tools/ceiling.py 2>&1 | grep -v amdgpu.ids > $O/mfma_ceiling.txt; cat $O/mfma_ceiling.txt ;;
     bound:*) timeout 400 python tools/forward_bound.py --size 512 ${stage#bound:} 2>&1 | grep -v amdgpu.ids > $O/forward_bound_$n.txt; head -8 $O/forward_bound_$n.txt ;;
+    fftrace:*) timeout 400 python tools/ff_trace.py ${stage#fftrace:} 2>&1 | grep -v amdgpu.ids > $O/ff_trace_$n.txt; cat $O/ff_trace_$n.txt ;;
     head) timeout 400 python tools/head_bench.py 2>&1 | grep -v amdgpu.ids > $O/head_bench.txt; cat $O/head_bench.txt ;;
     ab:*) timeout 600 python tools/ab_forward.py ${stage#ab:} 2>&1 | grep -v amdgpu.ids > $O/ab_forward_$n.txt; cat $O/ab_forward_$n.txt ;;
     vae_bound) timeout 600 python tools/vae_bound.py --frames 8 2>&1 | grep -v amdgpu.ids > $O/vae_bound.txt; cat $O/vae_bound.txt ;;
