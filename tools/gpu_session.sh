@@ -23,6 +23,8 @@
 #   emulate8         bench.py --emulate-world 8 (per-rank schedule of the 8-GPU long-clip job measured on one GPU)
 #   ceiling          tools/ceiling.py (MFMA-only probe + best-case 8192^3 GEMMs)
 #   bound:<args>     tools/forward_bound.py --size 512 <args> (e.g. "bound:--mfma-rate 1.25 --attn-rate 1.0")
+#   sh:<command>     any shell command (output -> sh_<n>.txt)
+#   fftrace:<modes>  tools/ff_trace.py <modes> (phase trace + ablations of the fused tail / head, tune library)
 #   head             tools/head_bench.py (fused block head vs the launches it replaces)
 #   ab:<settings>    tools/ab_forward.py <settings> (space-separated ops knobs, e.g. "ab:BLOCK_HEAD_FUSED=0 BLOCK_HEAD_FUSED=1")
 set -x
@@ -65,6 +67,7 @@ for stage in "$@"; do
     emulate8) (timeout 600 python bench.py --emulate-world 8 > $O/bench_emulate_world8.json 2> $O/bench_emulate_world8.err); head -c 3000 $O/bench_emulate_world8.json ;;
     ceiling) timeout 400 python tools/ceiling.py 2>&1 | grep -v amdgpu.ids > $O/mfma_ceiling.txt; cat $O/mfma_ceiling.txt ;;
     bound:*) timeout 400 python tools/forward_bound.py --size 512 ${stage#bound:} 2>&1 | grep -v amdgpu.ids > $O/forward_bound_$n.txt; head -8 $O/forward_bound_$n.txt ;;
+    sh:*) (timeout 900 bash -c "${stage#sh:}" 2>&1 | grep -v amdgpu.ids) > $O/sh_$n.txt; cat $O/sh_$n.txt ;;
     fftrace:*) timeout 400 python tools/ff_trace.py ${stage#fftrace:} 2>&1 | grep -v amdgpu.ids > $O/ff_trace_$n.txt; cat $O/ff_trace_$n.txt ;;
     head) timeout 400 python tools/head_bench.py 2>&1 | grep -v amdgpu.ids > $O/head_bench.txt; cat $O/head_bench.txt ;;
     ab:*) timeout 600 python tools/ab_forward.py ${stage#ab:} 2>&1 | grep -v amdgpu.ids > $O/ab_forward_$n.txt; cat $O/ab_forward_$n.txt ;;
