@@ -453,7 +453,7 @@ __device__ __forceinline__ int v_row_of_slot(int s) {
 template <int DT, int NW, int ABL = 0, int STAGE = 0, int PRIO = 0, int PIPE = 0>
 __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(const AttnArgs a) {
   constexpr int D = 40;
-  constexpr int NB = PIPE ? 4 : 3;          // ring depth (tiles t, t+1, t+2 [, t+3])
+  constexpr int NB = (PIPE == 1 || PIPE == 2) ? 4 : 3;   // ring depth (tiles t, t+1, t+2 [, t+3])
   constexpr int ROWB = 80;                  // K / V tile row pitch in bytes (= the row itself: the DMA image is lane-linear)
   constexpr int TILEB = KV_TILE * ROWB;     // 5120 B per tile
   constexpr int K_OFF = 0, V_OFF = NB * TILEB;
@@ -637,6 +637,13 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
 
   // S^T(x) = K.Q^T(x): 32 kv x 32 q per sub-tile u, three k-steps of 16 (the third carries the reference row)
   auto qk = [&](const uint4 (&kf)[2][3], int x, f32x16 (&st)[2]) {
+    if constexpr (ABL == 4) {  // (ablation: no MFMAs — scores from the operands' first registers so that the loads stay live)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[u][r] = -8.f + 1e-30f * (float)(kf[u][r % 3].x ^ qf[x][r % 3].y);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -649,7 +656,8 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k]), fast_exp2(st[u][2 * k + 1]));
+        if constexpr (ABL == 3) w[u][k] = pack2<DT>(st[u][2 * k] * 0.001f, st[u][2 * k + 1] * 0.001f);  // (ablation: no exponentials)
+        else w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k]), fast_exp2(st[u][2 * k + 1]));
         orr |= w[u][k];
       }
     return orr;
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     uint4 pa[2][2], pb[2][2];
     if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
     qk(kf, 0, sa);
-    qk(kf, 1, sb);
+    if constexpr (PIPE != 3) qk(kf, 1, sb);
     if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     // V^T fragments of the whole tile: 12 transposed reads issued now, waited for after the softmax (the compiler does
     // not track asm loads: the wait statement below names every destination)
@@ -769,6 +777,48 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
       }
 #undef MIMO_TR
     }
+    if constexpr (PIPE == 3) {
+      // Staggered query blocks (round 5, no extra registers, same tile granularity): the wave issues in order, so the scores of
+      // block B are multiplied while block A is exponentiated, and P.V of block A runs under the exponentials of block B:
+      //   Q.K^T(A) | Q.K^T(B) || exp(A) | P.V(A) || exp(B) | P.V(B)
+      __builtin_amdgcn_sched_barrier(0);
+      qk(kf, 1, sb);
+      const uint32_t ora = exp_pack(sa, wa);
+#define MIMO_SGB(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+      MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(11); MIMO_SGB(10); MIMO_SGB(10);
+#undef MIMO_SGB
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
+      to_frag(wa, pa);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vlo[2][0]), "+v"(vlo[2][1]),
+                     "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1]), "+v"(vhi[2][0]), "+v"(vhi[2][1])
+                   :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 vf = make_uint4(vlo[dt][u].x, vlo[dt][u].y, vhi[dt][u].x, vhi[dt][u].y);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ot[0][dt][j] = HT<DT>::mfma16(vf, pa[u][j], ot[0][dt][j]);
+        }
+      const uint32_t orb = exp_pack(sb, wb);
+#define MIMO_SGB(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x002, n, 1)
+      MIMO_SGB(6); MIMO_SGB(6); MIMO_SGB(6); MIMO_SGB(6); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5); MIMO_SGB(5);
+#undef MIMO_SGB
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(special | ((orb & 0x40004000u) != 0u)) != 0ull) slow(kf, 1, t, kv0, nk, wb);
+      to_frag(wb, pb);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 vf = make_uint4(vlo[dt][u].x, vlo[dt][u].y, vhi[dt][u].x, vhi[dt][u].y);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
+        }
+    } else {
     const uint32_t ora = exp_pack(sa, wa);
     const uint32_t orb = exp_pack(sb, wb);
     if (__builtin_amdgcn_ballot_w64(special | ((ora & 0x40004000u) != 0u)) != 0ull) slow(kf, 0, t, kv0, nk, wa);
@@ -789,11 +839,17 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
         const uint4 vf = make_uint4(vlo[dt][u].x, vlo[dt][u].y, vhi[dt][u].x, vhi[dt][u].y);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          ot[0][dt][j] = HT<DT>::mfma16(vf, pa[u][j], ot[0][dt][j]);
-          ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
+          if constexpr (ABL == 4) {  // (ablation: no MFMAs)
+            ot[0][dt][j][0] += 1e-30f * (float)(vf.x ^ pa[u][j].x);
+            ot[1][dt][j][0] += 1e-30f * (float)(vf.y ^ pb[u][j].y);
+          } else {
+            ot[0][dt][j] = HT<DT>::mfma16(vf, pa[u][j], ot[0][dt][j]);
+            ot[1][dt][j] = HT<DT>::mfma16(vf, pb[u][j], ot[1][dt][j]);
+          }
         }
       }
     if (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    }  // PIPE != 3
     if (t + 1 < T) {
       if (STAGE == 1) {
         if (t + 2 < T && ABL != 1) stage_write((CUR + 2) % NB);  // tile t+2: loaded at the top, readable after two barriers
@@ -953,7 +1009,7 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     }
   };
 
-  if constexpr (PIPE != 0) {
+  if constexpr (PIPE == 1 || PIPE == 2) {
     issue_tile(0, 0);
     if (T > 1) issue_tile(1, 1);
     if (T > 2) issue_tile(2, 2);
@@ -1548,6 +1604,14 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((attn40_kernel<DT, 4, 2>), grid, dim3(256), 0, st, a);
     return;
   }
+  if (tune_env("MIMO_ATTN40_ABLATE", 0) == 3) {  // no exponentials (results wrong): what the transcendental stream costs
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 3>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (tune_env("MIMO_ATTN40_ABLATE", 0) == 4) {  // no MFMAs (results wrong): what the matrix work costs
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 4>), grid, dim3(256), 0, st, a);
+    return;
+  }
   if (tune_env("MIMO_ATTN40_STAGE", 0) == 1 && nw == 4) {
     hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 1>), grid, dim3(256), 0, st, a);
     return;
@@ -1563,6 +1627,10 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   // its scratch traffic breaks the counted vmcnt waits (wrong results) — and is not instantiated.
   if (tune_env("MIMO_ATTN40_PIPE", 0) == 2) {
     hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0, 2>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (tune_env("MIMO_ATTN40_PIPE", 0) == 3) {  // staggered query blocks inside the tile (two waves per SIMD, no extra registers)
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0, 3>), grid, dim3(256), 0, st, a);
     return;
   }
 #endif

@@ -6,7 +6,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if any(k.startswith("MIMO_ATTN40_") for k in os.environ):  # variant knobs exist in the tune build only
+if any(k.startswith("MIMO_ATTN40_") for k in os.environ) or "--time" in sys.argv:  # variant knobs exist in the tune build only
     os.environ.setdefault("MIMO_HIP_LIB", os.path.join(ROOT, "mimo_amd", "libmimo_hip_tune.so"))
 from mimo_amd import ops  # noqa: E402
 

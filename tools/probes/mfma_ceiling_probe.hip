@@ -78,6 +78,82 @@ __global__ __launch_bounds__(512, 2) void valu_loop(float* sink, unsigned long l
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// How many VALU instructions hide behind one MFMA of the SAME wave?  Loop body: one v_mfma_f32_32x32x16_f16 (4 independent
+// accumulators round-robin) followed by NV independent VALU instructions (OP 0: v_exp_f32, 1: v_fma_f32, 2: v_cvt_pk_f16_f32).
+// Reports cycles per loop body (= per MFMA) for one wave; the MFMA alone is 32 cycles of its SIMD's matrix pipe.
+template <int OP, int NV>
+__global__ __launch_bounds__(512, 2) void mix_loop(const uint4* seed, float* sink, unsigned long long* cyc, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const f16x8 a = __builtin_bit_cast(f16x8, seed[tid & 4095]), b = __builtin_bit_cast(f16x8, seed[(tid + 77) & 4095]);
+  f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = acc3[r] = 0.f;
+  float x[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = -0.001f * (float)(threadIdx.x + i + 1);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#define MIX_VALU()                                                                 \
+  _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                  \
+    if (OP == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));                     \
+    else if (OP == 1) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x[i]));        \
+    else asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(x[i]));                  \
+  }
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+    MIX_VALU()
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+    MIX_VALU()
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+    MIX_VALU()
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+    MIX_VALU()
+#undef MIX_VALU
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += x[i];
+  s += acc0[0] + acc1[15] + acc2[3] + acc3[7];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int OP, int NV>
+static void mix_one(int cus, const uint4* seed, float* sink, unsigned long long* cyc, const char* name) {
+  const int iters = 4000;
+  double res[2];
+  for (int wps = 1; wps <= 2; ++wps) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL((mix_loop<OP, NV>), dim3(cus), dim3(256 * wps), 0, 0, seed, sink, cyc, iters);
+      hipDeviceSynchronize();
+    }
+    unsigned long long c[2048];
+    hipMemcpy(c, cyc, cus * 8, hipMemcpyDeviceToHost);
+    double cm = 0;
+    for (int i = 0; i < cus; ++i) cm += (double)c[i];
+    res[wps - 1] = cm / cus / ((double)iters * 4);
+  }
+  printf("1 MFMA 32x32x16 + %2d %-17s: %6.1f cycles per MFMA with one wave per SIMD, %6.1f with two (each wave; per SIMD: %.1f)\n", NV, name, res[0], res[1],
+         res[1] / 2);
+}
+
+static void mix_rates(int cus, const uint4* seed, float* sink, unsigned long long* cyc) {
+  printf("# in-wave overlap: cycles per (MFMA + NV VALU instructions of the same wave); the bare MFMA is 32 matrix-pipe cycles\n");
+  mix_one<1, 0>(cus, seed, sink, cyc, "(none)");
+  mix_one<1, 2>(cus, seed, sink, cyc, "v_fma_f32");
+  mix_one<1, 4>(cus, seed, sink, cyc, "v_fma_f32");
+  mix_one<1, 6>(cus, seed, sink, cyc, "v_fma_f32");
+  mix_one<1, 8>(cus, seed, sink, cyc, "v_fma_f32");
+  mix_one<1, 12>(cus, seed, sink, cyc, "v_fma_f32");
+  mix_one<0, 2>(cus, seed, sink, cyc, "v_exp_f32");
+  mix_one<0, 4>(cus, seed, sink, cyc, "v_exp_f32");
+  mix_one<0, 6>(cus, seed, sink, cyc, "v_exp_f32");
+  mix_one<0, 8>(cus, seed, sink, cyc, "v_exp_f32");
+  mix_one<0, 12>(cus, seed, sink, cyc, "v_exp_f32");
+  mix_one<2, 4>(cus, seed, sink, cyc, "v_cvt_pk_f16_f32");
+  mix_one<2, 8>(cus, seed, sink, cyc, "v_cvt_pk_f16_f32");
+}
+
 static void valu_rates(int cus, float* sink, unsigned long long* cyc) {
   const int iters = 20000;
   const char* names[4] = {"v_exp_f32", "v_fma_f32", "v_cvt_pk_f16_f32", "v_exp_f32 + v_fma_f32 (pair)"};
@@ -148,5 +224,6 @@ int main(int argc, char** argv) {
       }
   }
   valu_rates(cus, sink, cyc);
+  mix_rates(cus, seed, sink, cyc);
   return 0;
 }
