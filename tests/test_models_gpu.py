@@ -114,6 +114,77 @@ def test_motion_module(dev, dtype, C, F, hw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_level0_transformers_head_and_tail_fused_vs_oracle_and_unfused(dev, dtype):
+    """C = 320 at 16 x 16 (256 rows per image = two 128-row panels): the spatial transformer as head (GroupNorm-apply + proj_in +
+    norm1 + QKV) -> attention core -> tail, the motion module as head -> attention -> head (to_out + residual + LN + PE + QKV) ->
+    attention -> tail — forced onto the fused kernels (split-K off lifts their row threshold, as in the sharded mode) — against
+    the fp32 oracle AND against the same modules with BLOCK_HEAD_FUSED off (the launches the heads replace)."""
+    from mimo_amd import ops
+    from mimo_amd.modules import Ctx, MotionModule, SpatialTransformer
+    from oracle import models as OM, synth
+    C, heads, hw, b, F = 320, 8, 16, 2, 3
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(b, C, F, hw, hw, generator=g)
+    # spatial transformer, read mode
+    o = synth.build(OM.Transformer3DModel, 5, heads=heads, head_dim=C // heads, in_channels=C, cross_attention_dim=768)
+    p = SpatialTransformer(heads, C // heads, C, 768)
+    p.load_state_dict(o.state_dict(), strict=True)
+    p.to(dev)
+    ehs = torch.cat([torch.zeros(1, 1, 768), torch.randn(1, 1, 768, generator=g)])
+    bank = torch.randn(2, hw * hw, C, generator=g).to(torch.float16)
+    ob = o.transformer_blocks[0]
+    ob.mode, ob.bank, ob.do_cfg = "read", [bank], True
+    ref = o(x, ehs)
+    pb = p.transformer_blocks[0]
+    pb.mode = "read"
+    pb.attn2_slice = (0, C)
+    pb.set_bank(bank[1:].to(dev), dtype)
+    ctx = Ctx(dtype, b, F)
+    w, bias = pb.attn2_matrix()
+    ctx.attn2 = (ehs[:, 0].to(dev) @ w.t() + bias).contiguous()
+    xt = to_tok(x).to(dev)
+    with ops.split_k(False):
+        ops.COUNTER = {"flops": 0, "launches": 0}
+        out = p.run(ctx, xt)
+        n_fused = ops.COUNTER["launches"]
+        ops.BLOCK_HEAD_FUSED = False
+        try:
+            ops.COUNTER = {"flops": 0, "launches": 0}
+            out_u = p.run(ctx, xt)
+            n_unfused = ops.COUNTER["launches"]
+        finally:
+            ops.BLOCK_HEAD_FUSED = True
+            ops.COUNTER = None
+    assert n_fused < n_unfused, (n_fused, n_unfused)   # the head really ran (GroupNorm-apply, GEMM + LN and QKV GEMM became one)
+    e, eu = rel_l2(from_tok(out.cpu(), b, F), ref), rel_l2(out, out_u)
+    report(f"spatial transformer C320 16x16 head + tail fused {dtype}: rel_l2={e:.2e} (vs unfused head {eu:.2e}; {n_fused} vs {n_unfused} launches)")
+    assert e < TOL[dtype] and eu < TOL[dtype] / 2
+    # motion module
+    om = synth.build(OM.VanillaTemporalModule, 7, in_channels=C)
+    pm = MotionModule(C)
+    pm.load_state_dict(om.state_dict(), strict=True)
+    pm.to(dev)
+    refm = om(x)
+    with ops.split_k(False):
+        ops.COUNTER = {"flops": 0, "launches": 0}
+        outm = pm.run(Ctx(dtype, b, F), xt)
+        n_fused = ops.COUNTER["launches"]
+        ops.BLOCK_HEAD_FUSED = False
+        try:
+            ops.COUNTER = {"flops": 0, "launches": 0}
+            outm_u = pm.run(Ctx(dtype, b, F), xt)
+            n_unfused = ops.COUNTER["launches"]
+        finally:
+            ops.BLOCK_HEAD_FUSED = True
+            ops.COUNTER = None
+    assert n_fused < n_unfused, (n_fused, n_unfused)
+    e = rel_l2(from_tok(outm.cpu(), b, F) - x, refm - x)
+    eu = rel_l2(outm - xt, outm_u - xt)
+    report(f"motion module C320 16x16 F{F} heads + tail fused {dtype}: rel_l2(branch)={e:.2e} (vs unfused heads {eu:.2e}; {n_fused} vs {n_unfused} launches)")
+    assert e < TOL[dtype] and eu < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pose_guider(dev, dtype):
     og, pg = build_pair_pose(dtype, dev)
     x = torch.rand(1, 3, 3, 32, 40, generator=torch.Generator().manual_seed(4))
