@@ -845,6 +845,36 @@ def test_block_head_fused_c320(dev, dtype, M, variant):
     assert rel_l2(y, y3) < (ACC_TOL if not gn else 3e-4) and rel_l2(qkv.float(), q3.float()) < OUT_TOL[dtype]
 
 
+def test_block_head_fused_rejects_what_it_does_not_cover(dev):
+    """The C entry point validates its own arguments (MIMO_EINVAL -> MimoHipError): another width, both or neither operand,
+    an image / frame size that is not a whole number of 128-row panels, a misaligned QKV row stride."""
+    import ctypes
+    from mimo_amd import lib as L
+    C, M = 320, 1024
+    dt = torch.float16
+    ws = torch.zeros((4 * C, C), device=dev, dtype=dt)
+    a = torch.zeros((M, C), device=dev, dtype=dt)
+    x = torch.zeros((M, C), device=dev)
+    ab = torch.zeros((M // 512, 2, C), device=dev)
+    g = torch.ones((C,), device=dev)
+    y = torch.zeros((M, C), device=dev)
+    q = torch.zeros((M, 3 * C), device=dev, dtype=dt)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(A=None, X=None, AB=None, rpi=0, c=C, ldq=3 * C, pe=None, rpf=0, frames=0):
+        return L.call("mimo_block_head_fused", 0, None if A is None else A.data_ptr(), C, None if X is None else X.data_ptr(), C,
+                      None if AB is None else AB.data_ptr(), rpi, ws.data_ptr(), g.data_ptr(), None, 0, g.data_ptr(), g.data_ptr(), 1e-5,
+                      None if pe is None else pe.data_ptr(), rpf, frames, y.data_ptr(), C, q.data_ptr(), ldq, M, c, st)
+
+    call(A=a)                                  # fine
+    call(X=x, AB=ab, rpi=512)                  # fine
+    for bad in (dict(A=a, c=640), dict(A=a, X=x, AB=ab, rpi=512), dict(), dict(X=x, AB=ab, rpi=500), dict(X=x, rpi=512),
+                dict(A=a, ldq=3 * C + 4), dict(A=a, pe=g.repeat(4).view(4, C), rpf=100, frames=4)):
+        with pytest.raises(L.MimoHipError):
+            call(**bad)
+    torch.cuda.synchronize()
+
+
 def test_block_head_fused_is_batch_invariant(dev):
     """A row's y / qkv bits depend on that row, its image's affine, its frame's table row and the weights only: a CFG half
     (b = 1) alone equals the same rows of the b = 2 launch bit for bit."""
