@@ -651,6 +651,27 @@ def test_run_animate_frame_preparation():
     assert ref.size == (64, 64) and int(np.asarray(ref)[0, 0, 0]) == 255 and int(np.asarray(ref)[32, 32, 0]) == 7
 
 
+def test_video_io_round_trips_and_frame_selection(tmp_path):
+    """mimo_amd.video_io: the codec-free stand-ins of `load_video_fixed_fps` / `imageio.mimsave` — a directory of frames, lossless
+    animated WebP and APNG round-trip bit for bit and keep their frame rate; the selection is keep_frame_indices (pinned against the
+    reference's loader below); an mp4 path fails loudly without imageio."""
+    import numpy as np
+    from mimo_amd import video_io as V
+    from mimo_amd.run_edit import keep_frame_indices
+    rs = np.random.RandomState(0)
+    frames = [rs.randint(0, 256, (24, 40, 3), dtype=np.uint8) for _ in range(10)]
+    for name in ("clip_dir", "clip.webp", "clip.png"):
+        out = V.save_video(frames, str(tmp_path / name), fps=25)
+        back, fps = V.read_frames(out)
+        assert len(back) == 10 and abs(fps - 25.0) < 1e-6, (name, len(back), fps)
+        assert all(np.array_equal(np.asarray(b), f) for b, f in zip(back, frames)), name
+        sel = V.load_video_fixed_fps(out, target_fps=10)
+        idx = keep_frame_indices(10, 25.0, 10)
+        assert len(sel) == len(idx) and all(np.array_equal(np.asarray(a), frames[i]) for a, i in zip(sel, idx))
+    with pytest.raises((RuntimeError, FileNotFoundError, OSError)):
+        V.read_frames(str(tmp_path / "missing.mp4"))
+
+
 def test_run_edit_frame_selection_known_answers():
     """run_edit.keep_frame_indices / time_crop_range: the codec-free arithmetic of load_video_fixed_fps
     (tools/util.py:462-479) and of the time crop (run_edit.py:194-198)."""
