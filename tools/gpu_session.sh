@@ -12,6 +12,7 @@
 #   prof             rocprofv3 --kernel-trace --stats of the bench command -> bench_kernel_stats_rocprofv3.csv + JSON line
 #   pmc_traffic      FETCH_SIZE / WRITE_SIZE passes (separate) over tools/profile_forward.py -> pmc_forward_traffic.json
 #   pmc_sq           MFMA-busy / wave-state counters by kernel family  -> pmc_mfma_busy_by_family.txt
+#   pmc_clock        GRBM_GUI_ACTIVE / duration per kernel family = the effective (power-limited) shader clock
 #   pmc_lds          LDS bank-conflict counters by kernel family       -> pmc_lds_by_family.txt
 #   timeline         in-situ per-dispatch timeline of one forward      -> forward_timeline.txt
 #   bound            per-shape ceilings of the forward's launches      -> forward_bound_shapes_512.txt
@@ -53,6 +54,10 @@ for stage in "$@"; do
     pmc_sq) cd /tmp && export TMPDIR=/tmp
       (timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o s -- python $R/tools/profile_forward.py > $O/pmc_sq.log 2>&1)
       cd $R; Q=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1); python tools/pmc_family.py "$Q" > $O/pmc_mfma_busy_by_family.txt 2>&1; rm -rf $O/pmc_sq; cat $O/pmc_mfma_busy_by_family.txt ;;
+    pmc_clock) cd /tmp && export TMPDIR=/tmp
+      (timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_clk -o c -- python $R/tools/profile_forward.py > $O/pmc_clk.log 2>&1)
+      cd $R; Q=$(find $O/pmc_clk -name "*counter_collection.csv" | head -1); T=$(find $O/pmc_clk -name "*kernel_trace.csv" | head -1)
+      head -2 "$Q" > $O/pmc_clock_header.txt; (cd tools && python pmc_clock.py "$Q" "$T") > $O/pmc_clock_by_family.txt 2>&1; rm -rf $O/pmc_clk; cat $O/pmc_clock_by_family.txt ;;
     pmc_lds) cd /tmp && export TMPDIR=/tmp
       (timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_lds -o l -- python $R/tools/profile_forward.py > $O/pmc_lds.log 2>&1)
       cd $R; Q=$(find $O/pmc_lds -name "*counter_collection.csv" | head -1); python tools/pmc_family.py "$Q" > $O/pmc_lds_by_family.txt 2>&1; rm -rf $O/pmc_lds; cat $O/pmc_lds_by_family.txt ;;
