@@ -102,6 +102,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.  If this library were loaded first it would pull in
+    # the system runtime, torch would then allocate on one runtime and these kernels launch on the other (first launch fails
+    # with hipErrorNoDevice).  Importing torch first makes the loader resolve libamdhip64 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise MimoHipError(
             f"{LIB_PATH} is missing: build it with `python -m mimo_amd.build` "
