@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
       for (int k = 0; k < 8; ++k) {
         if constexpr (ABL == 3) w[u][k] = pack2<DT>(st[u][2 * k] * 0.001f, st[u][2 * k + 1] * 0.001f);  // (ablation: no exponentials)
         else w[u][k] = pack2<DT>(fast_exp2(st[u][2 * k]), fast_exp2(st[u][2 * k + 1]));
-        orr |= w[u][k];
+        orr |= w[u][k];  // (the compiler pairs these into v_or3_b32)
       }
     return orr;
   };
@@ -726,6 +726,7 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     }
   };
 
+  [[maybe_unused]] uint4 kf_carried[2][3];  // PIPE = 4: K fragments of the NEXT tile, loaded before the current tile's P.V MFMAs
   // ---- one KV tile; CUR (the ring slot it reads) is a compile-time constant ----
   auto tile = [&](auto cur_c, int t) {
     constexpr int CUR = decltype(cur_c)::value;
@@ -740,12 +741,15 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     const bool special = (t == 0) | (kv0 + KV_TILE > nk);  // wave-uniform: first / ragged tiles take the slow path
     const unsigned char* kbuf = smem + RD * TILEB;
 
-    uint4 kf[2][3];
+    uint4 kf_local[2][3];
+    uint4 (&kf)[2][3] = PIPE == 4 ? kf_carried : kf_local;   // PIPE = 4: the fragments were fetched under the previous tile's P.V
+    if constexpr (PIPE != 4) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB);
-      kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB + 32);
-      kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + RD * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
+      for (int u = 0; u < 2; ++u) {
+        kf[u][0] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB);
+        kf[u][1] = *reinterpret_cast<const uint4*>(kbuf + kaddr + u * 32 * ROWB + 32);
+        kf[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + RD * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
+      }
     }
     f32x16 sa[2], sb[2];
     uint32_t wa[2][8], wb[2][8];
@@ -830,6 +834,23 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
                    "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1]), "+v"(vhi[2][0]), "+v"(vhi[2][1])
                  :: "memory");
     __builtin_amdgcn_sched_barrier(0);  // no MFMA may be hoisted above the wait (cdna_hip_programming.md rule 18)
+    if constexpr (PIPE == 4) {
+      // Every LDS read of slot CUR is complete (K fragments before Q.K^T, V^T fragments just now): the tile's barrier moves
+      // HERE, in front of P.V, and the K fragments of tile t + 1 are requested right behind it — their LDS latency and the
+      // barrier skew hide under the 24 P.V MFMAs instead of standing in front of the next tile's first MFMA.
+      if (t + 1 < T) {
+        if (t + 2 < T) wait_all_but_newest();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        constexpr int NX = (CUR + 1) % NB;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          kf_carried[u][0] = *reinterpret_cast<const uint4*>(smem + NX * TILEB + kaddr + u * 32 * ROWB);
+          kf_carried[u][1] = *reinterpret_cast<const uint4*>(smem + NX * TILEB + kaddr + u * 32 * ROWB + 32);
+          kf_carried[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + NX * kaddr2_d + (h2 ? 0 : u * 32 * ROWB));
+        }
+      }
+    }
     // ---- O^T += V^T.P^T: d tiles {0..15, 16..31, 32..47}, two k-steps of 32 kv; every V^T fragment feeds 4 query tiles ----
     if (PRIO != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -850,7 +871,7 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
       }
     if (PRIO != 0) __builtin_amdgcn_s_setprio(0);
     }  // PIPE != 3
-    if (t + 1 < T) {
+    if (PIPE != 4 && t + 1 < T) {
       if (STAGE == 1) {
         if (t + 2 < T && ABL != 1) stage_write((CUR + 2) % NB);  // tile t+2: loaded at the top, readable after two barriers
       } else {
@@ -1061,6 +1082,14 @@ __global__ __launch_bounds__(64 * NW, PIPE == 2 ? 1 : 2) void attn40_kernel(cons
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();  // tiles 0 (and 1) and the constant slots are visible
+  if constexpr (PIPE == 4) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kf_carried[u][0] = *reinterpret_cast<const uint4*>(smem + kaddr + u * 32 * ROWB);
+      kf_carried[u][1] = *reinterpret_cast<const uint4*>(smem + kaddr + u * 32 * ROWB + 32);
+      kf_carried[u][2] = *reinterpret_cast<const uint4*>(smem + kaddr2_0 + (h2 ? 0 : u * 32 * ROWB));
+    }
+  }
 
   for (int t = 0; t < T; t += 3) {
     tile(IC2<0>{}, t);
@@ -1627,6 +1656,10 @@ static inline void attn40_launch(const AttnArgs& a, hipStream_t st) {
   // its scratch traffic breaks the counted vmcnt waits (wrong results) — and is not instantiated.
   if (tune_env("MIMO_ATTN40_PIPE", 0) == 2) {
     hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0, 2>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (tune_env("MIMO_ATTN40_PIPE", 0) == 4) {  // K fragments of the next tile fetched under P.V (barrier moved in front of P.V)
+    hipLaunchKernelGGL((attn40_kernel<DT, 4, 0, 0, 0, 4>), grid, dim3(256), 0, st, a);
     return;
   }
   if (tune_env("MIMO_ATTN40_PIPE", 0) == 3) {  // staggered query blocks inside the tile (two waves per SIMD, no extra registers)

@@ -154,6 +154,68 @@ static void mix_rates(int cus, const uint4* seed, float* sink, unsigned long lon
   mix_one<2, 8>(cus, seed, sink, cyc, "v_cvt_pk_f16_f32");
 }
 
+// Do the matrix pipe and the VALU of one SIMD run concurrently when the work comes from DIFFERENT waves?  Block = 8 waves; waves
+// w and w + 4 share a SIMD.  Waves 0-3 run an MFMA-only loop (mode bit 0), waves 4-7 a VALU-only loop of v_exp_f32 / v_fma_f32
+// (mode bit 1); wall time by hipEvents for MFMA waves alone, VALU waves alone, both.  Overlap: both ~= max; none: both ~= sum.
+template <int OP>
+__global__ __launch_bounds__(512, 2) void role_loop(const uint4* seed, float* sink, int iters_m, int iters_v, int mode) {
+  const int wave = threadIdx.x >> 6;
+  float s = 0.f;
+  if (wave < 4) {
+    if (!(mode & 1)) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const f16x8 a = __builtin_bit_cast(f16x8, seed[tid & 4095]), b = __builtin_bit_cast(f16x8, seed[(tid + 77) & 4095]);
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = acc3[r] = 0.f;
+    for (int it = 0; it < iters_m; ++it) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+    }
+    s = acc0[0] + acc1[15] + acc2[3] + acc3[7];
+  } else {
+    if (!(mode & 2)) return;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = -0.001f * (float)(threadIdx.x + i + 1);
+    for (int it = 0; it < iters_v; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (OP == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+        else asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x[i]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+  }
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+template <int OP>
+static void role_one(int cus, const uint4* seed, float* sink, const char* name, int iters_m, int iters_v) {
+  float ms[4] = {0, 0, 0, 0};
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int mode = 1; mode <= 3; ++mode)
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL((role_loop<OP>), dim3(cus), dim3(512), 0, 0, seed, sink, iters_m, iters_v, mode);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms[mode], e0, e1);
+    }
+  printf("MFMA waves alone %7.3f ms | %s waves alone %7.3f ms | both %7.3f ms  (sum %.3f, max %.3f)\n", ms[1], name, ms[2], ms[3], ms[1] + ms[2],
+         ms[1] > ms[2] ? ms[1] : ms[2]);
+}
+
+static void role_rates(int cus, const uint4* seed, float* sink) {
+  printf("# cross-wave concurrency of the matrix pipe and the VALU on one SIMD (waves w: MFMA 32x32x16 only, w + 4: VALU only)\n");
+  role_one<1>(cus, seed, sink, "v_fma_f32", 40000, 40000);   // 160k MFMAs x 32 cyc vs 320k fma x 8 cyc per wave
+  role_one<0>(cus, seed, sink, "v_exp_f32", 40000, 27000);
+}
+
 static void valu_rates(int cus, float* sink, unsigned long long* cyc) {
   const int iters = 20000;
   const char* names[4] = {"v_exp_f32", "v_fma_f32", "v_cvt_pk_f16_f32", "v_exp_f32 + v_fma_f32 (pair)"};
@@ -225,5 +287,6 @@ int main(int argc, char** argv) {
   }
   valu_rates(cus, sink, cyc);
   mix_rates(cus, seed, sink, cyc);
+  role_rates(cus, seed, sink);
   return 0;
 }
