@@ -158,9 +158,10 @@ static void mix_rates(int cus, const uint4* seed, float* sink, unsigned long lon
 // w and w + 4 share a SIMD.  Waves 0-3 run an MFMA-only loop (mode bit 0), waves 4-7 a VALU-only loop of v_exp_f32 / v_fma_f32
 // (mode bit 1); wall time by hipEvents for MFMA waves alone, VALU waves alone, both.  Overlap: both ~= max; none: both ~= sum.
 template <int OP>
-__global__ __launch_bounds__(512, 2) void role_loop(const uint4* seed, float* sink, int iters_m, int iters_v, int mode) {
+__global__ __launch_bounds__(512, 2) void role_loop(const uint4* seed, float* sink, unsigned long long* cyc, int iters_m, int iters_v, int mode) {
   const int wave = threadIdx.x >> 6;
   float s = 0.f;
+  const unsigned long long t0 = __builtin_readcyclecounter();
   if (wave < 4) {
     if (!(mode & 1)) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,30 +191,40 @@ __global__ __launch_bounds__(512, 2) void role_loop(const uint4* seed, float* si
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += x[i];
   }
+  const unsigned long long t1 = __builtin_readcyclecounter();
   if (s == 12345.678f) sink[threadIdx.x] = s;
+  if ((threadIdx.x & 255) == 0) cyc[blockIdx.x * 2 + (wave >> 2)] = t1 - t0;   // wave 0: MFMA role, wave 4: VALU role
 }
 
 template <int OP>
-static void role_one(int cus, const uint4* seed, float* sink, const char* name, int iters_m, int iters_v) {
+static void role_one(int cus, const uint4* seed, float* sink, unsigned long long* cyc, const char* name, int iters_m, int iters_v) {
   float ms[4] = {0, 0, 0, 0};
+  double cm[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int mode = 1; mode <= 3; ++mode)
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
-      hipLaunchKernelGGL((role_loop<OP>), dim3(cus), dim3(512), 0, 0, seed, sink, iters_m, iters_v, mode);
+      hipMemset(cyc, 0, cus * 16);
+      hipLaunchKernelGGL((role_loop<OP>), dim3(cus), dim3(512), 0, 0, seed, sink, cyc, iters_m, iters_v, mode);
       hipEventRecord(e1, 0);
       hipEventSynchronize(e1);
       hipEventElapsedTime(&ms[mode], e0, e1);
+      unsigned long long c[4096];
+      hipMemcpy(c, cyc, cus * 16, hipMemcpyDeviceToHost);
+      cm[mode] = cv[mode] = 0;
+      for (int i = 0; i < cus; ++i) { cm[mode] += (double)c[2 * i] / cus; cv[mode] += (double)c[2 * i + 1] / cus; }
     }
   printf("MFMA waves alone %7.3f ms | %s waves alone %7.3f ms | both %7.3f ms  (sum %.3f, max %.3f)\n", ms[1], name, ms[2], ms[3], ms[1] + ms[2],
          ms[1] > ms[2] ? ms[1] : ms[2]);
+  printf("    shader cycles of a wave (s_memtime): MFMA role alone %.3e, with the partner %.3e | VALU role alone %.3e, with the partner %.3e\n",
+         cm[1], cm[3], cv[2], cv[3]);
 }
 
-static void role_rates(int cus, const uint4* seed, float* sink) {
+static void role_rates(int cus, const uint4* seed, float* sink, unsigned long long* cyc) {
   printf("# cross-wave concurrency of the matrix pipe and the VALU on one SIMD (waves w: MFMA 32x32x16 only, w + 4: VALU only)\n");
-  role_one<1>(cus, seed, sink, "v_fma_f32", 40000, 40000);   // 160k MFMAs x 32 cyc vs 320k fma x 8 cyc per wave
-  role_one<0>(cus, seed, sink, "v_exp_f32", 40000, 27000);
+  role_one<1>(cus, seed, sink, cyc, "v_fma_f32", 40000, 40000);   // 160k MFMAs x 32 cyc vs 320k fma x 8 cyc per wave
+  role_one<0>(cus, seed, sink, cyc, "v_exp_f32", 40000, 27000);
 }
 
 static void valu_rates(int cus, float* sink, unsigned long long* cyc) {
@@ -287,6 +298,6 @@ int main(int argc, char** argv) {
   }
   valu_rates(cus, sink, cyc);
   mix_rates(cus, seed, sink, cyc);
-  role_rates(cus, seed, sink);
+  role_rates(cus, seed, sink, cyc);
   return 0;
 }
