@@ -298,10 +298,11 @@ int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* 
  *   qkv[M, 3C] (half) = (LayerNorm(y) * ln_gamma + ln_beta (+ ln_pe[(m / ln_rows_per_frame) % ln_pe_frames])) @ Wqkv^T
  *   A' = A (half16 [M, lda]: an attention output), or — A == NULL — half(x32 * a + b) with x32 the fp32 block input and
  *   gn_ab = fp32 [M / rows_per_img, 2, C] the GroupNorm folded to a per-(image, channel) affine (mimo_group_norm_affine):
- *   the normalised tensor never reaches memory (rows_per_img % 128 == 0: a 128-row panel lies inside one image).
+ *   the normalised tensor never reaches memory (rows_per_img >= 128: a 128-row panel holds rows of at most two images; the
+ *   reference's default 784 x 784 frames give 9604 rows per image).
  *   Wstream: half16 [4C, C] = [Wi with rows in tile order (pack_rows_tail) | [Wq; Wk; Wv] with its K axis permuted
  *   (pack_ff2_kperm)] (mimo_amd.packing.pack_block_head_stream); the LayerNorm output never reaches memory.
- *   ln_pe: NULL or fp32 [ln_pe_frames, C], ln_rows_per_frame % 128 == 0.  MIMO_EINVAL unless C == 320. */
+ *   ln_pe: NULL or fp32 [ln_pe_frames, C], ln_rows_per_frame >= 128.  MIMO_EINVAL unless C == 320. */
 int mimo_block_head_fused(int dtype, const void* A, int64_t lda, const float* x32, int64_t ldx, const float* gn_ab,
                           int64_t rows_per_img, const void* Wstream, const float* bi, const float* residual, int64_t ldr,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, const float* ln_pe,

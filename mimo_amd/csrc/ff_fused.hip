@@ -70,7 +70,7 @@ struct FFArgs {
   // MODE 3 / 4 (block head): W1 = ONE stream of 20 tiles of 64 rows [Wi (rows in tile order, K natural) | Wqkv (rows natural,
   // K permuted)]; A (half, MODE 3) or x + gn_ab (MODE 4) = the operand of the first projection; res optional; out32 = y;
   // out = qkv (half [M, ldo], 3C columns)
-  const float* gn_ab;     // MODE 4: fp32 [nimg, 2, C] GroupNorm folded to x * a + b per (image, channel); rows_per_img % 128 == 0
+  const float* gn_ab;     // MODE 4: fp32 [nimg, 2, C] GroupNorm folded to x * a + b per (image, channel); rows_per_img >= 128
   const float* ln_pe;     // optional fp32 [ln_pe_frames, C] added to the LayerNorm output, row = (m / ln_rows_per_frame) % frames
   int64_t ln_rows_per_frame;
   int ln_pe_frames;
@@ -250,25 +250,35 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         for (int ks = 0; ks < KS; ++ks)
           fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, 0));
     };
+    // Block head, per panel: LDS copies of what depends on the image / frame a row lies in.  A 128-row panel holds rows of at
+    // most TWO images / frames (rows_per_img, ln_rows_per_frame >= 128; they need not divide the panel — the reference's default
+    // 784 x 784 gives 9604 rows per image): slot set 0 for rows below the boundary, set 1 from it on.  Unused b1 slots of the
+    // bias image: [0, C) table row of frame 0, [C, 3C) a | b of image 0, [3C, 5C) a | b of image 1, [5C, 6C) table row of frame 1.
+    // Readers of the previous panel's copies are at least one of its QKV barriers behind.
+    [[maybe_unused]] int next_img = BM, next_frm = BM;   // first panel row of the second image / frame (BM: none)
     if constexpr (MODE == 4) {
-      // ---- block head on the fp32 block input: the GroupNorm in front of proj_in, folded to x * a + b per (image, channel),
-      // is applied while the operand is loaded.  a, b of the panel's image (a panel lies inside one image: rows_per_img % 128
-      // == 0) are staged in the unused b1 slots [C, 3C) of the bias image; the positional table row of the panel's frame (the
-      // motion module's LayerNorm + PE) in [0, C) likewise.  Readers of the previous panel's copies are at least one of
-      // its QKV barriers behind. ----
+      // the GroupNorm in front of proj_in, folded to x * a + b per (image, channel), is applied while the operand is loaded
       const int64_t img = M0 / g.rows_per_img;
-      if (tid < 2 * C / 4) {
+      const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
+      next_img = (int)((img + 1) * g.rows_per_img - M0 < BM ? (img + 1) * g.rows_per_img - M0 : BM);
+      if (tid < 4 * C / 4) {   // a | b of image img, then of image img + 1 (beyond the table: zeros, rows past M)
         const __amdgpu_buffer_rsrc_t rAB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)const_cast<float*>(g.gn_ab + img * 2 * C), 0, 2 * C * 4, 0x00020000);
+            (void*)const_cast<float*>(g.gn_ab + img * 2 * C), 0, (int)((nimg - img < 2 ? nimg - img : 2) * 2 * C * 4), 0x00020000);
         smem[BIAS_Q + (unsigned)(C / 4) + (unsigned)tid] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rAB, (unsigned)tid * 16u, 0, 0));
       }
     }
     if constexpr (HEAD) {
-      if (g.ln_pe && tid < C / 4) {
-        const int64_t frame = (M0 / g.ln_rows_per_frame) % g.ln_pe_frames;
-        const __amdgpu_buffer_rsrc_t rPE = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)const_cast<float*>(g.ln_pe + frame * C), 0, C * 4, 0x00020000);
-        smem[BIAS_Q + (unsigned)tid] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rPE, (unsigned)tid * 16u, 0, 0));
+      if (g.ln_pe) {
+        const int64_t f0 = M0 / g.ln_rows_per_frame;
+        next_frm = (int)((f0 + 1) * g.ln_rows_per_frame - M0 < BM ? (f0 + 1) * g.ln_rows_per_frame - M0 : BM);
+        if (tid < 2 * C / 4) {
+          const int second = tid >= C / 4;
+          const int64_t frame = (f0 + second) % g.ln_pe_frames;
+          const __amdgpu_buffer_rsrc_t rPE = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)const_cast<float*>(g.ln_pe + frame * C), 0, C * 4, 0x00020000);
+          smem[BIAS_Q + (unsigned)(second ? 5 * C / 4 : 0) + (unsigned)(tid - second * (C / 4))] =
+              __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rPE, (unsigned)(tid - second * (C / 4)) * 16u, 0, 0));
+        }
       }
     }
     if constexpr (MODE == 4) {
@@ -277,7 +287,10 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
           (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
       const unsigned x4_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + lg * 8) * 4));
       const unsigned x4_mi = (unsigned)(16 * g.ldx * 4);
-      const unsigned abq = pinned(BIAS_Q + (unsigned)(C / 4) + 2u * (unsigned)lg);
+      // this lane's rows: pr * 32 + 16 mi + li; the affine of the second image starts 2C floats further
+      const unsigned abq0 = BIAS_Q + (unsigned)(C / 4) + 2u * (unsigned)lg;
+      const unsigned abq_mi[2] = {pinned(abq0 + ((int)(pr * 32) + li >= next_img ? (unsigned)(2 * C / 4) : 0u)),
+                                  pinned(abq0 + ((int)(pr * 32) + 16 + li >= next_img ? (unsigned)(2 * C / 4) : 0u))};
       // four batches of 5 k-steps (10 loads of 16 B per lane), the next batch in flight while one is converted: all 40 loads
       // at once would need 160 registers (the compiler hoists them and spills)
       // (macros, not lambdas: arrays captured by reference two levels deep are not promoted to registers)
@@ -290,10 +303,10 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   __builtin_amdgcn_sched_barrier(0)
 #define FF_CONVERT_BATCH(buf, mi, k0)                                                                                           \
   _Pragma("unroll") for (int k = 0; k < KS / 2; ++k) {                                                                          \
-    const f32x4 a0 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(8 * ((k0) + k))]);                                          \
-    const f32x4 a1 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(8 * ((k0) + k) + 1)]);                                      \
-    const f32x4 b0 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(C / 4 + 8 * ((k0) + k))]);                                  \
-    const f32x4 b1 = __builtin_bit_cast(f32x4, smem[abq + (unsigned)(C / 4 + 8 * ((k0) + k) + 1)]);                              \
+    const f32x4 a0 = __builtin_bit_cast(f32x4, smem[abq_mi[mi] + (unsigned)(8 * ((k0) + k))]);                                          \
+    const f32x4 a1 = __builtin_bit_cast(f32x4, smem[abq_mi[mi] + (unsigned)(8 * ((k0) + k) + 1)]);                                      \
+    const f32x4 b0 = __builtin_bit_cast(f32x4, smem[abq_mi[mi] + (unsigned)(C / 4 + 8 * ((k0) + k))]);                                  \
+    const f32x4 b1 = __builtin_bit_cast(f32x4, smem[abq_mi[mi] + (unsigned)(C / 4 + 8 * ((k0) + k) + 1)]);                              \
     const f32x4 y0 = __builtin_elementwise_fma(buf[2 * k], a0, b0), y1 = __builtin_elementwise_fma(buf[2 * k + 1], a1, b1);      \
     uint32_t w0 = pack2<DT>(y0[0], y0[1]), w1 = pack2<DT>(y0[2], y0[3]), w2 = pack2<DT>(y1[0], y1[1]), w3 = pack2<DT>(y1[2], y1[3]); \
     asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); /* materialise HERE: the optimiser otherwise sinks the conversion to the first use and keeps x, a, b live */ \
@@ -414,7 +427,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
           const unsigned cq = (unsigned)(4 * (2 * kk + h));
           const f32x4 gm = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(11 * C / 4) + cq]);
           f32x4 bt = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(12 * C / 4) + cq]);
-          if constexpr (HEAD) bt += __builtin_bit_cast(f32x4, smem[bcol + cq]);  // + pe[frame] (zeros without a table)
+          if constexpr (HEAD)  // + pe[frame of this row] (zeros without a table)
+            bt += __builtin_bit_cast(f32x4, smem[bcol + cq + ((int)(pr * 32) + 16 * mi + li >= next_frm ? (unsigned)(5 * C / 4) : 0u)]);
           const f32x4 v = (acc2[2 * kk + h][mi] - mean[mi]) * rstd[mi] * gm + bt;
           w[2 * h] = pack2<DT>(v[0], v[1]);
           w[2 * h + 1] = pack2<DT>(v[2], v[3]);
@@ -840,10 +854,10 @@ extern "C" int mimo_block_head_fused(int dtype, const void* A, int64_t lda, cons
                                      int64_t ldq, int64_t M, int C_, void* stream) {
   if ((!A) == (!x32) || !Wstream || !ln_gamma || !ln_beta || !y_out || !qkv || M <= 0) return MIMO_EINVAL;
   if (C_ != C) return MIMO_EINVAL;
-  if (x32 && (!gn_ab || rows_per_img < BM || (rows_per_img % BM) || (ldx & 3) || !aligned16(x32) || !aligned16(gn_ab))) return MIMO_EINVAL;
+  if (x32 && (!gn_ab || rows_per_img < BM || (ldx & 3) || !aligned16(x32) || !aligned16(gn_ab))) return MIMO_EINVAL;   // (<= two images per panel)
   if (A && ((lda & 7) || !aligned16(A))) return MIMO_EINVAL;
   if (residual && ((ldr & 3) || !aligned16(residual))) return MIMO_EINVAL;
-  if (ln_pe && (ln_rows_per_frame < BM || (ln_rows_per_frame % BM) || ln_pe_frames <= 0 || !aligned16(ln_pe))) return MIMO_EINVAL;
+  if (ln_pe && (ln_rows_per_frame < BM || ln_pe_frames <= 0 || !aligned16(ln_pe))) return MIMO_EINVAL;   // (<= two frames per panel)
   if ((ldy & 3) || (ldq & 7) || !aligned16(Wstream) || !aligned16(y_out) || !aligned16(qkv)) return MIMO_EINVAL;
   if ((A && ((M - 1) * lda + C) * 2 >= 0x80000000LL) || (x32 && ((M - 1) * ldx + C) * 4 >= 0x100000000LL) ||
       (residual && ((M - 1) * ldr + C) * 4 >= 0x100000000LL) || ((M - 1) * ldy + C) * 4 >= 0x100000000LL ||

@@ -334,9 +334,9 @@ def _ff_proj_run(ctx, p, y_f32, n3, proj, x_f32, colstats):
 
 
 def _head_fusable(ws, M, HW):
-    """mimo_block_head_fused applies: C = 320 (a packed stream exists), whole 128-row panels per image / frame, and the
+    """mimo_block_head_fused applies: C = 320 (a packed stream exists), at most two images / frames per 128-row panel, and the
     row-count rule of the fused tails (a function of the layer and the frame size, never of the batch beyond the threshold)."""
-    return ops.BLOCK_HEAD_FUSED and ops.BLOCK_TAIL_FUSED and ops.FF_FUSED and ws is not None and HW % 128 == 0 and \
+    return ops.BLOCK_HEAD_FUSED and ops.BLOCK_TAIL_FUSED and ops.FF_FUSED and ws is not None and HW >= 128 and \
         M <= ops.FF_FUSED_MAX_ROWS and (M >= ops.FF_FUSED_MIN_ROWS or not ops.split_k_enabled())
 
 

@@ -365,12 +365,12 @@ def block_head_fused(wstream, bi, ln_gamma, ln_beta, ln_eps, *, a=None, x=None, 
         assert a.dtype == dtype
     else:
         assert x.dtype == torch.float32 and gn_ab is not None and gn_ab.dtype == torch.float32 and gn_ab.is_contiguous()
-        assert gn_ab.shape == (M // rows_per_img, 2, C) and M % rows_per_img == 0 and rows_per_img % 128 == 0
+        assert gn_ab.shape == (M // rows_per_img, 2, C) and M % rows_per_img == 0 and rows_per_img >= 128
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, C) and residual.stride(1) == 1
     if pe is not None:
         assert pe.dtype == torch.float32 and pe.is_contiguous() and pe.shape[1] == C and pe.shape[0] >= pe_frames > 0
-        assert rows_per_frame % 128 == 0
+        assert rows_per_frame >= 128
     y = torch.empty((M, C), device=src.device, dtype=torch.float32)
     qkv = torch.empty((M, 3 * C), device=src.device, dtype=dtype)
     fl = 2 * M * C * (C + 3 * C)

@@ -792,13 +792,15 @@ def test_block_tail_fused_c320(dev, dtype, M, rows_per_img):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,variant", [(1024, "gn"), (4096 * 3, "gn_pe"), (128, "a"), (8192 + 77, "a_res"), (33, "a_res"), (2048, "a_res_pe")])
+@pytest.mark.parametrize("M,variant", [(1024, "gn"), (4096 * 3, "gn_pe"), (128, "a"), (8192 + 77, "a_res"), (33, "a_res"), (2048, "a_res_pe"),
+                                       (5 * 456, "gn_pe_straddle"), (7 * 200 + 19, "a_res_pe_straddle")])
 def test_block_head_fused_c320(dev, dtype, M, variant):
     """mimo_block_head_fused (C = 320): (GroupNorm-apply +) projection (+ residual) -> y (fp32, written), LayerNorm (+ positional
     table) -> QKV in one launch, vs a torch fp32 reference that rounds to half where the kernel does (the normalised input, the
     LayerNorm output) and vs the three launches it replaces (GroupNorm-apply, GEMM + fused LayerNorm, QKV GEMM).
     Variants: gn = fp32 block input + GroupNorm affine (the spatial transformer's head), gn_pe = + positional table (the motion
-    module's first head), a* = half operand (an attention output) with residual / table (its second head); ragged M."""
+    module's first head), a* = half operand (an attention output) with residual / table (its second head); ragged M;
+    *_straddle: rows per image / frame that do not divide the 128-row panel (panels hold rows of two images / frames)."""
     from mimo_amd import ops
     from mimo_amd.packing import pack_block_head_stream
     C = 320
@@ -809,8 +811,9 @@ def test_block_head_fused_c320(dev, dtype, M, variant):
     gamma = 1 + rnd((C,), dev, torch.float32, 13, 0.2)
     beta = rnd((C,), dev, torch.float32, 14, 0.2)
     ws = pack_block_head_stream(wi, wqkv, dtype)
-    rpi = 512 if gn else 0                      # rows per image (GroupNorm affine) = rows per frame (positional table)
-    rpf, frames = (rpi or 256), 3
+    straddle = "straddle" in variant            # image / frame sizes that do not divide the 128-row panel (784 x 784 gives 9604)
+    rpi = (456 if straddle else 512) if gn else 0   # rows per image (GroupNorm affine) = rows per frame (positional table)
+    rpf, frames = (rpi or (200 if straddle else 256)), 3
     pe = rnd((5, C), dev, torch.float32, 15, 0.5) if pe_on else None
     res = (rnd((M, C), dev, torch.float32, 16) + 0.5) if res_on else None
     kw = dict(residual=res, pe=pe, rows_per_frame=rpf if pe_on else 0, pe_frames=frames if pe_on else 0)
@@ -868,7 +871,7 @@ def test_block_head_fused_rejects_what_it_does_not_cover(dev):
 
     call(A=a)                                  # fine
     call(X=x, AB=ab, rpi=512)                  # fine
-    for bad in (dict(A=a, c=640), dict(A=a, X=x, AB=ab, rpi=512), dict(), dict(X=x, AB=ab, rpi=500), dict(X=x, rpi=512),
+    for bad in (dict(A=a, c=640), dict(A=a, X=x, AB=ab, rpi=512), dict(), dict(X=x, AB=ab, rpi=100), dict(X=x, rpi=512),
                 dict(A=a, ldq=3 * C + 4), dict(A=a, pe=g.repeat(4).view(4, C), rpf=100, frames=4)):
         with pytest.raises(L.MimoHipError):
             call(**bad)
