@@ -1252,6 +1252,92 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   tile_epilogue<DT, NR, MT, BM, true>(g, acc, M0, N0, wr, wc, lg, li, 0u);
 }
 
+// Dense GEMM whose tile holds WHOLE rows at N = 640 (level 1 of the UNets), so that the LayerNorm that follows the projection
+// (attention.py:329-360 norm1 / norm3 after proj_in / to_out; motion_module.py:230-258 norms + positional table) rides in its
+// epilogue (tile_epilogue_ln) and the separate LayerNorm pass — a full read of the fp32 tensor — disappears (round 5).
+// A 64 x 640 tile with the 64-deep K-tile of gemm_kernel would need 2 x 90 KB of LDS; here the K-tile is ONE MFMA k-step (32):
+// a 16-row x 64-byte piece is 1 KB = one LDS-DMA instruction, stored in MFMA fragment order (the lane that will read a 16-byte
+// chunk is the lane that fetches it): fragment reads are contiguous, conflict-free, and nothing is swizzled.  8 waves side by side (64 rows x 80 columns each: MT = 4, NR = 5, 80 accumulator
+// registers), 3-deep ring of 44 KB slots, one barrier per K-tile, counted vmcnt (5 W pieces per wave and K-tile + 1 A piece for
+// waves 0-3).  The launch is bound by its epilogue traffic (residual in, fp32 + half out), not by the matrix pipe.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm_ln640_kernel(const GemmArgs g) {
+  constexpr int NR = 5, MT = 4, BM = 64, BN = 640, KT = 32, NST = 3;
+  constexpr int A_BYTES = BM * KT * 2, W_BYTES = BN * KT * 2, SLOT = A_BYTES + W_BYTES;   // 4 KB + 40 KB
+  __shared__ __attribute__((aligned(16))) uint4 smem[(NST * SLOT + 2 * BM * 8 * 4) / 16];  // ONE LDS object: ring | LayerNorm row sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = (int)wave_u;
+  const int lg = lane >> 4, li = lane & 15;
+  const int64_t M0 = (int64_t)blockIdx.x * BM;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const int nkt = g.K / KT;
+
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  const i32x4 rA = make_rsrc(g.A + M0 * g.lda, (unsigned)(((rows_valid - 1) * g.lda + g.K) * 2));   // rows beyond M: zero fill
+  const i32x4 rW = make_rsrc(g.W, g.w_bytes);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+  // piece = 16 tile rows x 64 B = 1 KB.  The DMA writes lane-linear, and the MFMA fragment of lane (li, lg) is row li, chunk lg:
+  // lane l = 16 lg + li FETCHES row l & 15, 16-byte chunk l >> 4, so that a piece in LDS is already in fragment order
+  // (fragment reads are one contiguous, conflict-free KB)
+  const unsigned a_lane = (unsigned)((lane & 15) * g.lda * 2 + (lane >> 4) * 16);
+  const unsigned w_lane = (unsigned)((lane & 15) * g.ldw * 2 + (lane >> 4) * 16);
+  const bool has_a = wave_u < 4u;   // waves 0-3 also move one of the four A pieces
+  auto dma = [&](const i32x4& r, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory", "m0");
+  };
+  constexpr unsigned OOBA = 0x80000000u;
+  auto issue = [&](int kt) {   // K-tile kt into slot kt % NST (past the end: zero-fill DMAs keep the counts uniform)
+    const bool live = kt < nkt;
+    const unsigned slot = smem_base + (unsigned)((kt % NST) * SLOT);
+    const unsigned kw = (unsigned)(kt * KT * 2);
+    if (has_a) dma(rA, live ? a_lane + wave_u * (unsigned)(16 * g.lda * 2) : OOBA, kw, slot + wave_u * 1024u);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const unsigned p = wave_u + 8u * (unsigned)i;   // W piece: rows 16 p .. 16 p + 15
+      dma(rW, live ? w_lane + p * (unsigned)(16 * g.ldw * 2) : OOBA, kw, slot + (unsigned)A_BYTES + p * 1024u);
+    }
+  };
+  auto wait_all_but_newest = [&]() {
+    if (has_a) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  };
+
+  f32x4 acc[NR][MT];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  issue(1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_all_but_newest();   // tile kt has landed (this wave's part); tile kt + 1 may stay in flight
+    __syncthreads();         // ... every wave's part, and every wave is done reading slot (kt + 2) % 3 = (kt - 1) % 3
+    issue(kt + 2);
+    const uint4* sa = &smem[((kt % NST) * SLOT) / 16];
+    const uint4* sb = sa + A_BYTES / 16;
+    uint4 fa[MT], fb[NR];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) fa[mi] = sa[mi * 64 + lane];                    // piece mi in fragment order (row li, chunk lg at 16 lane)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) fb[ni] = sb[(wn * NR + ni) * 64 + lane];
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = HT<DT>::mfma16(fb[ni], fa[mi], acc[ni][mi]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs must not outlive the block's LDS
+  __syncthreads();                                   // (the row-sum exchange reuses no ring bytes, but keep the epilogue behind every MFMA read)
+  tile_epilogue_ln<DT, NR, MT, BM, 8>(g, acc, M0, 0, wn, lg, li, reinterpret_cast<float*>(&smem[(NST * SLOT) / 16]));
+}
+
 // Split-K reduction + the full epilogue: out = epi(sum_s partial[s]); one thread per 4 consecutive columns.
 template <int DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, int splits) {
@@ -1381,6 +1467,11 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   // fused LayerNorm output: the tile must hold whole rows (N == 320 = the NR = 5 XL8 width), dense only
   if (g.ln_out) {
     if constexpr (MODE == 0 && NR == 5) {
+      if (g.N == 640 && !geglu && !g.colstats && (g.K % 32) == 0 && g.M < 0x7fffffffLL * 64) {   // whole rows at N = 640: 64-row tiles
+        hipLaunchKernelGGL((gemm_ln640_kernel<DT>), dim3((unsigned)((g.M + 63) / 64)), dim3(512), 0, st, g);
+        MIMO_LAUNCH_CHECK();
+        return MIMO_OK;
+      }
       if (g.N != 64 * NR || geglu || g.colstats) return MIMO_EINVAL;
       g.tiles_n = 1;
       const int64_t nwg = (g.M + 127) / 128;

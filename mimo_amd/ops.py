@@ -198,6 +198,12 @@ def _is_f32(t):
     raise L.MimoHipError(f"unsupported tensor dtype {t.dtype}")
 
 
+# The LayerNorm after an N = 640 projection in the GEMM's epilogue (gemm_ln640_kernel: 64 x 640 whole-row tiles).  OFF: measured
+# SLOWER than GEMM + LayerNorm launch (166.6 vs 125.3 us at M49152 K640, 391.6 vs 222.5 at K2560, profiles/r5_ln640_bench.txt) —
+# a 64-row block streams the whole 640 x K weight through LDS-DMA, which fills at ~12 B/clk per CU.  Kept for the record and tested.
+LN_OUT_640 = False
+
+
 def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f32=False, silu=False,
          geglu=False, out=None, out_scale=1.0, colstats=False, ln=None):
     """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1).
@@ -205,7 +211,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     colstats=<rows per image>: also emit GroupNorm column statistics of `out` (attached as out._cs) when the image size
     allows (see COLSTATS_MIN_HW).
     ln=dict(gamma, beta[, eps, pe, rows_per_frame, pe_frames]): also return LayerNorm(out) (+ pe) as a half tensor —
-    fused into the epilogue when N == 320, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out)."""
+    fused into the epilogue when N == 320 or 640, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out)."""
     _chk(a, "a")
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
     assert a.dtype == w.dtype
@@ -229,8 +235,9 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
         ldib = img_bias.stride(0)
     if not _SPLIT_K:
         flags |= L.EPI_NO_SPLITK
-    fuse_ln = (ln is not None and N == 320 and not geglu and not silu and out.stride(0) == N and out.is_contiguous()
-               and (residual is None or ldr == N)
+    # N = 320: 128-row whole-row tiles of the persistent kernel; N = 640 (round 5, LN_OUT_640): 64-row tiles of gemm_ln640_kernel
+    fuse_ln = (ln is not None and (N == 320 or (N == 640 and LN_OUT_640 and K % 32 == 0)) and not geglu and not silu
+               and out.stride(0) == N and out.is_contiguous() and (residual is None or ldr == N)
                and (ln.get("pe") is None or (ln.get("rows_per_frame", 0) % 128 == 0 and ln.get("pe_frames", 0) > 0)))
     cs = ln_out = None
     if not fuse_ln and not geglu and N % 4 == 0 and _want_colstats(colstats, M):

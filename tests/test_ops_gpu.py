@@ -621,6 +621,58 @@ def test_gemm_fused_layer_norm_output(dev, dtype, M, K, with_res, with_pe):
     assert rel_l2(y2.float(), F.layer_norm(a.float() @ w2.float().t(), (640,), g2, be2, 1e-5)) < OUT_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,with_res,with_pe,with_ib", [(4096, 640, True, True, False), (1000, 640, True, False, True), (8192 + 64, 2560, False, True, False),
+                                                          (70, 64, True, False, False), (49152, 640, True, False, True)])
+def test_gemm_fused_layer_norm_output_n640(dev, dtype, M, K, with_res, with_pe, with_ib):
+    """The same at N = 640 (level 1): gemm_ln640_kernel — 64 x 640 whole-row tiles, K-tile 32, 3-deep ring — fp32 output (+ bias,
+    per-image bias, residual) and LayerNorm (+ positional table) as the second, half output; ragged M; equal to the unfused pair."""
+    from mimo_amd import ops
+    N, HW, Fr = 640, 128, 4
+    a = rnd((M, K), dev, dtype, 1)
+    w = rnd((N, K), dev, dtype, 2, K ** -0.5)
+    b = rnd((N,), dev, torch.float32, 3)
+    res = rnd((M, N), dev, torch.float32, 4) * 1.5 + 0.2 if with_res else None
+    g = rnd((N,), dev, torch.float32, 5) * 0.1 + 1
+    be = rnd((N,), dev, torch.float32, 6) * 0.1
+    pe = rnd((32, N), dev, torch.float32, 7) if with_pe else None
+    rpi = 250 if M == 1000 else 1024
+    ib = rnd(((M + rpi - 1) // rpi, N), dev, torch.float32, 8) if with_ib else None
+    ln = dict(gamma=g, beta=be, eps=1e-5)
+    if with_pe:
+        ln.update(pe=pe, rows_per_frame=HW, pe_frames=Fr)
+    kw = dict(bias=b, residual=res, out_f32=True, img_bias=ib, rows_per_img=rpi if with_ib else 0)
+    ops.LN_OUT_640 = True   # (off by default: correct but slower than the two launches, see mimo_amd/ops.py)
+    try:
+        out, y = ops.gemm(a, w, ln=ln, **kw)
+    finally:
+        ops.LN_OUT_640 = False
+    ref_out = a.float() @ w.float().t() + b + (res if with_res else 0)
+    if with_ib:
+        ref_out = ref_out + ib[torch.arange(M, device=dev) // rpi]
+    assert rel_l2(out, ref_out) < ACC_TOL
+    ref_y = F.layer_norm(ref_out, (N,), g, be, 1e-5)
+    if with_pe:
+        ref_y = ref_y + pe[(torch.arange(M, device=dev) // HW) % Fr]
+    assert y.dtype == dtype and rel_l2(y.float(), ref_y) < OUT_TOL[dtype]
+    for sl in (slice(0, 1), slice(M - 1, M), slice(M // 2, M // 2 + 1)):
+        assert rel_l2(y[sl].float(), ref_y[sl]) < 2 * OUT_TOL[dtype]
+    for c in (0, 79, 80, 319, 320, 639):
+        assert rel_l2(y[:, c].float(), ref_y[:, c]) < 2 * OUT_TOL[dtype] and rel_l2(out[:, c], ref_out[:, c]) < 10 * ACC_TOL
+    # the unfused pair behind the same interface (the default)
+    out_u, y_u = ops.gemm(a, w, ln=ln, **kw)
+    assert rel_l2(out, out_u) < 1e-6 and rel_l2(y.float(), y_u.float()) < OUT_TOL[dtype]
+    # a row's bits do not depend on the launch it is computed in
+    half = (M // 2) // 64 * 64
+    if half and not with_pe and not with_ib:
+        ops.LN_OUT_640 = True
+        try:
+            o2, y2 = ops.gemm(a[:half].contiguous(), w, ln=ln, bias=b, residual=None if res is None else res[:half].contiguous(), out_f32=True)
+        finally:
+            ops.LN_OUT_640 = False
+        assert torch.equal(o2, out[:half]) and torch.equal(y2, y[:half])
+
+
 def sdpa_ref(q, k, v, heads):
     B, Nq, C = q.shape
     d = C // heads
