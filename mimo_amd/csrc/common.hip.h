@@ -5,6 +5,14 @@
 #include <stdint.h>
 #include "mimo_hip.h"
 
+// cache-policy experiment (tools/_ab builds): aux bits of the streaming buffer loads / stores (2 = nt)
+#ifndef MIMO_LD_AUX
+#define MIMO_LD_AUX 0
+#endif
+#ifndef MIMO_ST_AUX
+#define MIMO_ST_AUX 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

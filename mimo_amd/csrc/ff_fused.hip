@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, 0));
+          fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, MIMO_LD_AUX));
     };
     // Block head, per panel: LDS copies of what depends on the image / frame a row lies in.  A 128-row panel holds rows of at
     // most TWO images / frames (rows_per_img, ln_rows_per_frame >= 128; they need not divide the panel — the reference's default
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       f32x4 xb0[KS], xb1[KS];
 #define FF_LOAD_BATCH(buf, mi, k0)                                                                                              \
   _Pragma("unroll") for (int k = 0; k < KS / 2; ++k) {                                                                          \
-    buf[2 * k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128, (mi) * x4_mi, 0));          \
-    buf[2 * k + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128 + 16, (mi) * x4_mi, 0)); \
+    buf[2 * k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128, (mi) * x4_mi, MIMO_LD_AUX));          \
+    buf[2 * k + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX4, x4_off + ((k0) + k) * 128 + 16, (mi) * x4_mi, MIMO_LD_AUX)); \
   }                                                                                                                             \
   __builtin_amdgcn_sched_barrier(0)
 #define FF_CONVERT_BATCH(buf, mi, k0)                                                                                           \
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((MODE >= 2 ? 10 : 8) * C / 4 + 4 * nt)]);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, 0)) + bv;
+        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, MIMO_LD_AUX)) + bv;
     }
     // one 64-row tile of a [C, C] weight in the W1 region of stage t & 1 (rows in the tile order of pack_proj_tail: this
     // wave's output columns 32 q .. 32 q + 31 of its 160 are the tile's n-tiles 2 sh, 2 sh + 1) times the operand in fa
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         for (int nt = 0; nt < 10; ++nt)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rT, o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rT, o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, MIMO_ST_AUX);
       }
       ln_operand();
       FF_TRACE(g, tr, 18);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
           const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
           const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
           const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rQ, q_off + 32u * (unsigned)ni, (unsigned)q * 128u, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rQ, q_off + 32u * (unsigned)ni, (unsigned)q * 128u, MIMO_ST_AUX);
         }
         ++t;
         FF_TRACE(g, tr, 6);
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         // even 16-lane rows: row tile 0, columns 4 lg .. 4 lg + 7; odd rows: row tile 1, columns 4 (lg - 1) ..
         const unsigned row = (unsigned)(row0 + (lg & 1) * 16);
         const unsigned c8 = 160u * sh + 16u * (unsigned)nt + 4u * (unsigned)(lg & ~1);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, MIMO_ST_AUX);
       }
     } else {
       // ---- the block's output projection: out32 = x + z @ Wp^T + bp, z = the FF result just accumulated (fp32, this wave:
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(9 * C / 4 + 4 * nt)]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
-          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, 0)) + bv;
+          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, MIMO_LD_AUX)) + bv;
       }
       // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, issue the next, multiply
       proj(ICf<0>{});
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
-                                                 o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, 0);
+                                                 o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, MIMO_ST_AUX);
       // ---- optional: GroupNorm column statistics of out32, per 32-row slab = exactly this wave's rows: (mean, sum of squared
       // deviations from that mean) per column, an exact two-pass computation on the values still in registers (sum over the two
       // row tiles, then over the 16 rows of a tile by DPP, fixed order), in the layout of mimo_gemm_ext's colstats.  The norm

@@ -132,7 +132,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
   const int row0 = wm * 16 * MT + li;       // tile-local row of mi = 0
   const int col0 = wn * 16 * NR + 4 * lg;   // tile-local column of ni = 0, r = 0
   auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MIMO_LD_AUX));
   };
 
   auto epilogue = [&](auto has_res_c, auto has_imgb_c, auto geglu_c) {
@@ -168,7 +168,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
 #pragma unroll
           for (int ni = 0; ni < NR; ++ni) {
             const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(
-                r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 2u : OOB, 0, 0);
+                r_res, col_ok[ni] ? (row * (unsigned)g.ldr + (unsigned)(N0 + col0 + ni * 16)) * 2u : OOB, 0, MIMO_LD_AUX);
             rr[ni] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
                              HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
           }
@@ -194,12 +194,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
         const int no = GEGLU ? (N0 + wn * 16 * NR + ni * 16) / 2 + 4 * lg : N0 + col0 + ni * 16;  // output column
         const unsigned ooff = col_ok[ni] ? (row * (unsigned)g.ldo + (unsigned)no) * esz_o : OOB;
         if (out_f32) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, MIMO_ST_AUX);
         } else {
           u32x2 o;
           o.x = pack2<DT>(v[0], v[1]);
           o.y = pack2<DT>(v[2], v[3]);
-          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, MIMO_ST_AUX);
         }
       }
     }
@@ -252,7 +252,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
             if (res_f32) {
               v[u] += ld4(r_res, okc ? (row * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
             } else {
-              const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc ? (row * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+              const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc ? (row * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, MIMO_LD_AUX);
               v[u] += (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
                               HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
             }
@@ -265,7 +265,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
         // even 16-lane rows: row mi0, columns 4 lg .. 4 lg + 7; odd rows: row mi0 + 1, columns 4 (lg - 1) ..
         const unsigned row = (unsigned)(row0 + (mi0 + (lg & 1)) * 16);
         const unsigned ooff = (int)c8 < n_out ? (row * (unsigned)g.ldo + c8) * 2u : OOB;  // n_out % 8 == 0
-        __builtin_amdgcn_raw_buffer_store_b128(o, r_out, ooff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r_out, ooff, 0, MIMO_ST_AUX);
       }
     }
   };
@@ -333,7 +333,7 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmArgs& g, f32x4 (&a
   const int row0 = wm * 16 * MT + li;
   const int col0 = wn * 16 * NR + 4 * lg;
   auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MIMO_LD_AUX));
   };
 #pragma unroll
   for (int sp = 0; sp < MT / 2; ++sp) {
@@ -363,8 +363,8 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmArgs& g, f32x4 (&a
           ra[ni] = ld4(r_res, okc[ni] ? (rowa * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
           rb[ni] = ld4(r_res, okc[ni] ? (rowb * (unsigned)g.ldr + (unsigned)n) * 4u : OOB);
         } else {
-          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowa * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
-          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowb * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, 0);
+          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowa * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, MIMO_LD_AUX);
+          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, okc[ni] ? (rowb * (unsigned)g.ldr + (unsigned)n) * 2u : OOB, 0, MIMO_LD_AUX);
           ra[ni] = (f32x4){HT<DT>::to_f((uint16_t)(ha.x & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.x >> 16)),
                            HT<DT>::to_f((uint16_t)(ha.y & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.y >> 16))};
           rb[ni] = (f32x4){HT<DT>::to_f((uint16_t)(hb.x & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.x >> 16)),
@@ -386,14 +386,14 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmArgs& g, f32x4 (&a
       const unsigned oa = okc[ni] ? (rowa * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
       const unsigned ob = okc[ni] ? (rowb * (unsigned)g.ldo + (unsigned)n) * esz_o : OOB;
       if (out_f32) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va[ni]), r_out, oa, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb[ni]), r_out, ob, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va[ni]), r_out, oa, 0, MIMO_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb[ni]), r_out, ob, 0, MIMO_ST_AUX);
       } else {
         u32x2 o;
         o.x = pack2<DT>(va[ni][0], va[ni][1]); o.y = pack2<DT>(va[ni][2], va[ni][3]);
-        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, oa, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, oa, 0, MIMO_ST_AUX);
         o.x = pack2<DT>(vb[ni][0], vb[ni][1]); o.y = pack2<DT>(vb[ni][2], vb[ni][3]);
-        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ob, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ob, 0, MIMO_ST_AUX);
       }
     }
     // 3: slab statistics (32 rows = rows li of tile a + rows li of tile b) while the stores drain
@@ -450,7 +450,7 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
   const int row0 = wm * 16 * MT + li;
   const int col0 = wn * 16 * NR + 4 * lg;
   auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MIMO_LD_AUX));
   };
   // ---- 1: the ordinary epilogue; the stored values stay in `acc`.  All loads first, then all stores: interleaved
   // they serialise (vmcnt retires in order, a load behind a store waits for the store's acknowledgement) ----
@@ -469,7 +469,7 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
           if (res_f32) {
             rr[ni][mi] = ld4(r_res, (row * (unsigned)g.ldr + n) * 4u);
           } else {
-            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, (row * (unsigned)g.ldr + n) * 2u, 0, 0);
+            const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(r_res, (row * (unsigned)g.ldr + n) * 2u, 0, MIMO_LD_AUX);
             rr[ni][mi] = (f32x4){HT<DT>::to_f((uint16_t)(h.x & 0xffffu)), HT<DT>::to_f((uint16_t)(h.x >> 16)),
                                  HT<DT>::to_f((uint16_t)(h.y & 0xffffu)), HT<DT>::to_f((uint16_t)(h.y >> 16))};
           }
@@ -488,11 +488,11 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
         acc[ni][mi] = v;
         const unsigned ooff = (row * (unsigned)g.ldo + n) * esz_o;
         if (out_f32) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, ooff, 0, MIMO_ST_AUX);
         } else {
           u32x2 o;
           o.x = pack2<DT>(v[0], v[1]); o.y = pack2<DT>(v[2], v[3]);
-          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(o, r_out, ooff, 0, MIMO_ST_AUX);
         }
       }
     }
@@ -564,7 +564,7 @@ __device__ __forceinline__ void tile_epilogue_ln(const GemmArgs& g, f32x4 (&acc)
       const u32x4 o16 = {sx[0], sy[0], sx[1], sy[1]};
       const unsigned row = (unsigned)(row0 + (mi + (lg & 1)) * 16);
       const unsigned c8 = (unsigned)(wn * 16 * NR + ni * 16 + 4 * (lg & ~1));
-      __builtin_amdgcn_raw_buffer_store_b128(o16, r_ln, (row * (unsigned)g.N + c8) * 2u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o16, r_ln, (row * (unsigned)g.N + c8) * 2u, 0, MIMO_ST_AUX);
     }
   }
 }
