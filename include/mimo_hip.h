@@ -95,6 +95,15 @@ int mimo_gemm(int dtype, const void* A, int64_t lda, const void* W, void* out, i
  *             result (src/models/attention.py:329-360,391-429; src/models/motion_module.py:230-258,276-279).
  *             mimo_gemm_ext only; needs N == 320 (one tile holds whole rows), ldo == N, no SILU/GEGLU, and with
  *             ln_pe: ln_rows_per_frame % 128 == 0.  Other shapes: call mimo_layer_norm.
+ *   LayerNorm folded into the CONSUMING projection (C = 640 / 1280, where no tile holds a whole row; the same
+ *   nn.LayerNorm sites as ln_out): LayerNorm(x) . W^T + b = rstd * (x . (gamma o W)^T - mean * colsum) + (beta . W^T + b).
+ *     producer (the GEMM that writes x: proj_in / to_out + residual; fp32 out, no SILU / GEGLU, mimo_row_stat_slots(N) > 0):
+ *       row_half   half16 [M, N]: the stored rows rounded to the operand type — the consumer's A operand
+ *       row_stats  fp32 [M][mimo_row_stat_slots(N)][2]: per row and column slot (sum, sum of squares) of the rounded values
+ *     consumer (to_q/k/v, GEGLU proj; any epilogue): A = row_half, W = half(gamma o W), bias = beta . W^T + b and
+ *       a_row_stats (the producer's row_stats), a_slots = mimo_row_stat_slots(K), a_colsum fp32 [N] = sum_k W[n, k] of
+ *       the ROUNDED weight, a_eps: v = rstd[m] * (acc - mean[m] * a_colsum[n]) in front of the ordinary epilogue.
+ *   Neither half splits K.  The slot layout is a function of N alone, so a row's statistics do not depend on the batch.
  * --------------------------------------------------------------------------------- */
 typedef struct mimo_epilogue_ext {
   float* colstats;
@@ -105,7 +114,16 @@ typedef struct mimo_epilogue_ext {
   float ln_eps;
   int ln_pe_frames;
   int64_t ln_rows_per_frame;
+  void* row_half;
+  float* row_stats;
+  const float* a_row_stats;
+  const float* a_colsum;
+  int a_slots;
+  float a_eps;
 } mimo_epilogue_ext;
+
+/* number of column slots of row_stats for a producer of width N (0: the folded form does not cover N) */
+int mimo_row_stat_slots(int N);
 
 int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
                   int64_t M, int N, int K, const float* bias, const float* img_bias,

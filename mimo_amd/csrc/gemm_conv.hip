@@ -70,6 +70,13 @@ struct GemmArgs {
   float ln_eps;
   int64_t ln_rows_per_frame;
   int ln_pe_frames;
+  // LayerNorm folded into the consuming GEMM (mimo_epilogue_ext row_half / row_stats / a_row_stats / a_colsum)
+  void* row_half;            // producer: half16 [M, N] copy of the stored rows (ld = N)
+  float* row_stats;          // producer: [M][N / slot width][2] = (sum, sum of squares) of the ROUNDED values of each column slot
+  const float* a_row_stats;  // consumer: the row_stats of A's rows ([M][a_slots][2]); v = rstd * (acc - mean * a_colsum[n])
+  const float* a_colsum;     // consumer: [N] = sum over k of W[n, k]
+  int a_slots;
+  float a_eps;
   unsigned long long* dbg;  // MIMO_TUNE builds: cycle-counter trace of block 0 (null otherwise)
 };
 
@@ -101,7 +108,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- epilogue of one output tile: lane holds out[m = M0 + .. + li][n = N0 + .. + 4*lg + r], r = 0..3 ----
-template <int DT, int NR, int MT, int BM, bool PAIR = true>
+// PAIR_IMGB: half output with a per-image bias also takes the paired 16-byte-store form (its bias rows are fetched one row
+// pair ahead, in front of the previous pair's stores) — the QKV projections with a folded LayerNorm + positional table
+template <int DT, int NR, int MT, int BM, bool PAIR = true, bool PAIR_IMGB = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0, const int N0,
                                               const int wm, const int wn, const int lg, const int li,
                                               const unsigned ysplit) {
@@ -221,9 +230,31 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
       const int n = N0 + col0 + ni * 16;
       bv[ni] = ld4(r_bias, n < g.N ? (unsigned)n * 4u : OOB);
     }
+    // the per-image bias rows of a row pair are fetched while the previous pair is being stored (a load issued behind a
+    // store would wait for the store's acknowledgement: vmcnt retires in order)
+    auto ib_load = [&](int mi, int ni) -> f32x4 {
+      const unsigned row = (unsigned)(row0 + mi * 16);
+      const int n = N0 + col0 + ni * 16;
+      return ld4(r_imgb, n < g.N ? ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + (unsigned)n * 4u : OOB);
+    };
+    [[maybe_unused]] f32x4 ibc[2][NR], ibn[2][NR];
+    if constexpr (HAS_IMGB) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ni = 0; ni < NR; ++ni) ibc[u][ni] = ib_load(u, ni);
+    }
     // rows outer, column groups inner: consecutive stores fill the two rows of the pair left to right
 #pragma unroll
     for (int mi0 = 0; mi0 < MT; mi0 += 2) {
+      if constexpr (HAS_IMGB) {
+        if (mi0 + 2 < MT) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ni = 0; ni < NR; ++ni) ibn[u][ni] = ib_load(mi0 + 2 + u, ni);
+        }
+      }
 #pragma unroll
       for (int ni = 0; ni < NR; ni += (GEGLU ? 2 : 1)) {
         if (GEGLU && ni + 1 >= NR) break;
@@ -237,8 +268,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
           const int mi = mi0 + u;
           const unsigned row = (unsigned)(row0 + mi * 16);
           v[u] = acc[ni][mi] + bv[ni];
-          if (HAS_IMGB)
-            v[u] += ld4(r_imgb, okc ? ((unsigned)(M0 + row) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u + (unsigned)n * 4u : OOB);
+          if (HAS_IMGB) v[u] += ibc[u][ni];
           if (GEGLU) {
             const int ng = ni + 1 < NR ? ni + 1 : ni;
             const f32x4 gt = acc[ng][mi] + bv[ng];
@@ -267,6 +297,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
         const unsigned ooff = (int)c8 < n_out ? (row * (unsigned)g.ldo + c8) * 2u : OOB;  // n_out % 8 == 0
         __builtin_amdgcn_raw_buffer_store_b128(o, r_out, ooff, 0, MIMO_ST_AUX);
       }
+      if constexpr (HAS_IMGB) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ni = 0; ni < NR; ++ni) ibc[u][ni] = ibn[u][ni];
+      }
     }
   };
   // (GEGLU and the 16-wave tiles keep the per-row form: 128 registers per wave, the paired form spills there)
@@ -277,6 +313,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
       epilogue_pair(IC<0>{}, IC<0>{}, IC<0>{});
       return;
     }
+    if constexpr (PAIR_IMGB) {
+      if (!out_f32 && pair16 && !geglu && !g.res && g.img_bias) {
+        epilogue_pair(IC<0>{}, IC<1>{}, IC<0>{});
+        return;
+      }
+    }
   }
   if (geglu) epilogue(IC<0>{}, IC<0>{}, IC<1>{});
   else if (g.res && g.img_bias) epilogue(IC<1>{}, IC<1>{}, IC<0>{});
@@ -285,6 +327,187 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
   else epilogue(IC<0>{}, IC<0>{}, IC<0>{});
 }
 
+
+// ---- LayerNorm folded into the CONSUMING GEMM (round 5; C = 640 / 1280, where no tile holds a whole row) ----
+// LayerNorm(x) . W^T = rstd * (x . (gamma o W)^T - mean * colsum(gamma o W)) + beta . W^T: the consumer multiplies the RAW rows
+// (rounded to half: `row_half`) by the gamma-scaled weight and applies mean / rstd per row in its epilogue, so the
+// normalised tensor is never written and the fp32 tensor never re-read.  The producer of x leaves, next to its fp32 result,
+// the half copy and per row the (sum, sum of squares) of the rounded values of every column slot; a slot is the 16 NR
+// columns one wave owns (a function of N only: row_slot_width), so the partials and their fixed summation order are the
+// same whatever tile height or kernel the row count selects.
+template <int DT, int NR, int MT, int BM>
+__device__ __forceinline__ void tile_epilogue_rowside(const GemmArgs& g, f32x4 (&acc)[NR][MT], const int64_t M0, const int N0,
+                                                      const int wm, const int wn, const int lg, const int li) {
+  // The producer's whole epilogue, two MFMA row tiles at a time (so the accumulators retire as they are stored):
+  // v = acc + bias (+ per-image bias) (+ residual), * out_scale -> fp32 `out`; half(v) -> `row_half` in 16-byte stores through
+  // the lane exchange of tile_epilogue; (sum, sum of squares) of the rounded values of this wave's 16 NR columns -> `row_stats`.
+  static_assert(MT % 2 == 0, "rows are stored in pairs of MFMA tiles");
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const bool res_f32 = g.flags & MIMO_EPI_RES_F32;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const unsigned esz_r = res_f32 ? 4u : 2u;
+  const int slots = g.N / (16 * NR);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.out + M0 * g.ldo * 4, 0, (int)(((rows_valid - 1) * g.ldo + g.N) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)const_cast<void*>(g.res) + M0 * g.ldr * esz_r, 0,
+      g.res ? (int)(((rows_valid - 1) * g.ldr + g.N) * esz_r) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  const int64_t nimg = g.img_bias ? (g.M + g.rows_per_img - 1) / g.rows_per_img : 0;
+  const __amdgpu_buffer_rsrc_t r_imgb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.img_bias), 0, g.img_bias ? (int)(((nimg - 1) * g.ldib + g.N) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)g.row_half + M0 * g.N * 2, 0, (int)(rows_valid * g.N * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g.row_stats + M0 * slots * 2), 0, (int)(rows_valid * slots * 8), 0x00020000);
+  const int row0 = wm * 16 * MT + li;
+  const int colw = N0 + wn * 16 * NR;        // first column of this wave's slot (N % (16 NR) == 0: every column is valid)
+  const unsigned slot = (unsigned)(colw / (16 * NR));
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MIMO_LD_AUX));
+  };
+#pragma unroll
+  for (int sp = 0; sp < MT / 2; ++sp) {
+    const unsigned rowa = (unsigned)(row0 + (2 * sp) * 16), rowb = rowa + 16u;
+    unsigned imga = 0, imgb = 0;
+    if (g.img_bias) {
+      imga = ((unsigned)(M0 + rowa) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+      imgb = ((unsigned)(M0 + rowb) / (unsigned)g.rows_per_img) * (unsigned)g.ldib * 4u;
+    }
+    // 1: every load of the row pair back to back (vmcnt retires in order: a load behind a store waits for the store)
+    f32x4 va[NR], vb[NR], ra[NR], rb[NR];
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const unsigned n = (unsigned)(colw + ni * 16 + 4 * lg);
+      const f32x4 bv = ld4(r_bias, n * 4u);
+      va[ni] = acc[ni][2 * sp] + bv;
+      vb[ni] = acc[ni][2 * sp + 1] + bv;
+      if (g.img_bias) {
+        va[ni] += ld4(r_imgb, imga + n * 4u);
+        vb[ni] += ld4(r_imgb, imgb + n * 4u);
+      }
+      if (g.res) {
+        if (res_f32) {
+          ra[ni] = ld4(r_res, (rowa * (unsigned)g.ldr + n) * 4u);
+          rb[ni] = ld4(r_res, (rowb * (unsigned)g.ldr + n) * 4u);
+        } else {
+          const u32x2 ha = __builtin_amdgcn_raw_buffer_load_b64(r_res, (rowa * (unsigned)g.ldr + n) * 2u, 0, MIMO_LD_AUX);
+          const u32x2 hb = __builtin_amdgcn_raw_buffer_load_b64(r_res, (rowb * (unsigned)g.ldr + n) * 2u, 0, MIMO_LD_AUX);
+          ra[ni] = (f32x4){HT<DT>::to_f((uint16_t)(ha.x & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.x >> 16)),
+                           HT<DT>::to_f((uint16_t)(ha.y & 0xffffu)), HT<DT>::to_f((uint16_t)(ha.y >> 16))};
+          rb[ni] = (f32x4){HT<DT>::to_f((uint16_t)(hb.x & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.x >> 16)),
+                           HT<DT>::to_f((uint16_t)(hb.y & 0xffffu)), HT<DT>::to_f((uint16_t)(hb.y >> 16))};
+        }
+      }
+    }
+    // 2: finish, store fp32, round, store the half copy, accumulate the slot's sums
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+      const unsigned n = (unsigned)(colw + ni * 16 + 4 * lg);
+      if (g.res) { va[ni] += ra[ni]; vb[ni] += rb[ni]; }
+      va[ni] *= g.out_scale;
+      vb[ni] *= g.out_scale;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va[ni]), r_out, (rowa * (unsigned)g.ldo + n) * 4u, 0, MIMO_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb[ni]), r_out, (rowb * (unsigned)g.ldo + n) * 4u, 0, MIMO_ST_AUX);
+      const unsigned la = pack2<DT>(va[ni][0], va[ni][1]), ha = pack2<DT>(va[ni][2], va[ni][3]);
+      const unsigned lb = pack2<DT>(vb[ni][0], vb[ni][1]), hb = pack2<DT>(vb[ni][2], vb[ni][3]);
+      {
+        const float h0 = HT<DT>::to_f((uint16_t)(la & 0xffffu)), h1 = HT<DT>::to_f((uint16_t)(la >> 16));
+        const float h2 = HT<DT>::to_f((uint16_t)(ha & 0xffffu)), h3 = HT<DT>::to_f((uint16_t)(ha >> 16));
+        s1a += (h0 + h1) + (h2 + h3);
+        s2a += fmaf(h0, h0, h1 * h1) + fmaf(h2, h2, h3 * h3);
+      }
+      {
+        const float h0 = HT<DT>::to_f((uint16_t)(lb & 0xffffu)), h1 = HT<DT>::to_f((uint16_t)(lb >> 16));
+        const float h2 = HT<DT>::to_f((uint16_t)(hb & 0xffffu)), h3 = HT<DT>::to_f((uint16_t)(hb >> 16));
+        s1b += (h0 + h1) + (h2 + h3);
+        s2b += fmaf(h0, h0, h1 * h1) + fmaf(h2, h2, h3 * h3);
+      }
+      // even 16-lane rows end up with row a, columns 4 lg .. 4 lg + 7; odd ones with row b, columns 4 (lg - 1) ..
+      const auto sx = __builtin_amdgcn_permlane16_swap(la, lb, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(ha, hb, false, false);
+      const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+      const unsigned row = (lg & 1) ? rowb : rowa;
+      const unsigned c8 = (unsigned)(colw + ni * 16 + 4 * (lg & ~1));
+      __builtin_amdgcn_raw_buffer_store_b128(o, r_h, (row * (unsigned)g.N + c8) * 2u, 0, MIMO_ST_AUX);
+    }
+    // 3: the four lanes li, li + 16, li + 32, li + 48 hold the four column quads of a row: (q0 + q1) + (q2 + q3) everywhere
+    s1a += __shfl_xor(s1a, 16); s2a += __shfl_xor(s2a, 16); s1b += __shfl_xor(s1b, 16); s2b += __shfl_xor(s2b, 16);
+    s1a += __shfl_xor(s1a, 32); s2a += __shfl_xor(s2a, 32); s1b += __shfl_xor(s1b, 32); s2b += __shfl_xor(s2b, 32);
+    u32x2 st;
+    st.x = __builtin_bit_cast(unsigned, s1a); st.y = __builtin_bit_cast(unsigned, s2a);
+    __builtin_amdgcn_raw_buffer_store_b64(st, r_s, lg == 0 ? (rowa * (unsigned)slots + slot) * 8u : OOB, 0, 0);
+    st.x = __builtin_bit_cast(unsigned, s1b); st.y = __builtin_bit_cast(unsigned, s2b);
+    __builtin_amdgcn_raw_buffer_store_b64(st, r_s, lg == 0 ? (rowb * (unsigned)slots + slot) * 8u : OOB, 0, 0);
+  }
+}
+
+// the consumer half: acc <- rstd[m] * (acc - mean[m] * colsum[n]) in front of the ordinary epilogue (bias = beta . W^T + b,
+// GEGLU, ...).  Nothing of it may wait on memory in the epilogue (a tile lives ~25 us; fetched there — four lanes of every wave
+// of a block row each loading a row's partials — the statistics cost 45-75 us per launch, and even one exposed L2 round
+// trip + two barriers per tile cost 10-20 us): a row's partial sums (K columns in a_slots <= 20 slots) are fetched by ONE
+// thread per row when the block starts, summed left to right while the prologue's DMAs are in flight, and (mean, rstd) of
+// the BM rows and the colsum of the BN columns wait in a small LDS region of their own (3 KB) for the epilogue.
+constexpr int ROW_STAT_LOADS = 10;   // 16-byte loads = two slots each
+
+__device__ __forceinline__ void row_stats_issue(const GemmArgs& g, const int64_t M0, const int N0, const int BM, const int BN, const int tid,
+                                                u32x4 (&q)[ROW_STAT_LOADS], u32x4& cq) {
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+  const unsigned slots = (unsigned)g.a_slots;
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.a_row_stats ? g.a_row_stats + M0 * slots * 2 : nullptr), 0,
+      g.a_row_stats ? (int)(rows_valid * slots * 8) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)const_cast<float*>(g.a_colsum), 0, g.a_colsum ? g.N * 4 : 0, 0x00020000);
+  const unsigned base = (unsigned)tid * slots * 8u;
+#pragma unroll
+  for (int p = 0; p < ROW_STAT_LOADS; ++p)
+    q[p] = __builtin_amdgcn_raw_buffer_load_b128(r_s, (tid < BM && 2u * (unsigned)p < slots) ? base + (unsigned)p * 16u : OOB, 0, 0);
+  const int n = N0 + 4 * tid;   // thread tid < BN / 4: four columns of the tile
+  cq = __builtin_amdgcn_raw_buffer_load_b128(r_c, (4 * tid < BN && n < g.N) ? (unsigned)n * 4u : OOB, 0, 0);
+}
+
+// thread tid < BM: (mean, rstd) of row tid -> mr[2 tid ..]; thread tid < BN / 4: colsum of columns 4 tid .. -> cs[4 tid ..]
+__device__ __forceinline__ void row_stats_finish(const GemmArgs& g, const int BM, const int BN, const int tid,
+                                                 const u32x4 (&q)[ROW_STAT_LOADS], const u32x4& cq, float* mr, float* cs) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < ROW_STAT_LOADS; ++p) {   // (slots beyond a_slots were out of range: + 0)
+    const f32x4 v = __builtin_bit_cast(f32x4, q[p]);
+    s1 += v[0]; s2 += v[1];
+    s1 += v[2]; s2 += v[3];
+  }
+  const float inv_k = 1.0f / (float)g.K;
+  const float mean = s1 * inv_k;
+  const float var = fmaxf(fmaf(-mean, mean, s2 * inv_k), 0.f);
+  if (tid < BM) {
+    mr[2 * tid] = mean;
+    mr[2 * tid + 1] = rsqrtf(var + g.a_eps);
+  }
+  if (4 * tid < BN) *reinterpret_cast<u32x4*>(cs + 4 * tid) = cq;
+}
+
+template <int NR, int MT>
+__device__ __forceinline__ void tile_row_affine(f32x4 (&acc)[NR][MT], const int wm, const int wn, const int lg, const int li,
+                                                const float* mr, const float* cs) {
+  const int row0 = wm * 16 * MT + li;
+  const int col0 = wn * 16 * NR + 4 * lg;
+  float mean[MT], rstd[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    mean[mi] = mr[2 * (row0 + mi * 16)];
+    rstd[mi] = mr[2 * (row0 + mi * 16) + 1];
+  }
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cs + col0 + ni * 16);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = (acc[ni][mi] - mean[mi] * c) * rstd[mi];
+  }
+}
 
 // sum over the 16 lanes of a DPP row (= the 16 rows `li` of one MFMA tile that share a column chunk): four
 // v_add_f32_dpp, every lane ends up with the total, fixed order (deterministic)
@@ -584,7 +807,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   constexpr int LOADS = NAJ + NBJ;                    // DMAs per thread per K-tile
   static_assert(BM % PASS == 0, "A tile must be a whole number of DMA passes");
   constexpr int STAGE = (BM + BNA) * 8;               // 16-byte units per ring slot: [A tile | B tile]
-  constexpr int LNRED = EPI == 1 ? (2 * BM * WN) / 4 : 0;  // 16-byte units of the LayerNorm row-sum exchange
+  constexpr int LNRED = EPI == 1 ? (2 * BM * WN) / 4       // 16-byte units of the LayerNorm row-sum exchange
+                        : EPI == 2 ? (2 * BM + BN) / 4     // ... of the folded LayerNorm's (mean, rstd) per row and colsum per column
+                                   : 0;
   // ONE LDS object (a second __shared__ array would make hipcc drain vmcnt before fragment reads)
   __shared__ __attribute__((aligned(16))) uint4 smem[NSTAGE * STAGE + LNRED];
 
@@ -599,6 +824,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   const int tile_n = (int)(L % (unsigned)g.tiles_n);
   const int64_t M0 = (int64_t)tile_m * BM;
   const int N0 = tile_n * BN;
+  [[maybe_unused]] u32x4 rsq[EPI == 2 ? ROW_STAT_LOADS : 1], csq;
+  if constexpr (EPI == 2) row_stats_issue(g, M0, N0, BM, BN, tid, rsq, csq);   // (all out of range without a_row_stats)
 
   // ---- staging roles: thread -> (row srow + PASS*j, physical 16-byte chunk tid&7) ----
   // The DMA writes lane-linear (wave-uniform base + lane*16), so the lane that fills physical chunk (tid&7) of
@@ -898,6 +1125,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
   MIMO_TRACE(g, tr, 1);
 #pragma unroll
   for (int i = 0; i < NSTAGE - 1; ++i) load_tile(kt_lo + i, i);
+  if constexpr (EPI == 2) {   // (the K loop's barriers order these LDS writes before the epilogue's reads)
+    if (g.a_row_stats) {
+      float* mr = reinterpret_cast<float*>(&smem[NSTAGE * STAGE]);
+      row_stats_finish(g, BM, BN, tid, rsq, csq, mr, mr + 2 * BM);
+    }
+  }
   for (int kt = kt_lo; kt < kt_hi; kt += NSTAGE) {
     step(IC<0>{}, kt);
     if (kt + 1 < kt_hi) step(IC<1 % NSTAGE>{}, kt + 1);
@@ -908,6 +1141,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(const
 
   if constexpr (EPI == 1) {
     tile_epilogue_ln<DT, NR, MT, BM, WN>(g, acc, M0, wm, wn, lg, li, reinterpret_cast<float*>(&smem[NSTAGE * STAGE]));
+  } else if constexpr (EPI == 2) {  // LayerNorm folded into the consumer: the instantiations that carry its two halves
+    if (g.a_row_stats) {
+      const float* mr = reinterpret_cast<const float*>(&smem[NSTAGE * STAGE]);
+      tile_row_affine<NR, MT>(acc, wm, wn, lg, li, mr, mr + 2 * BM);
+    }
+    bool done = false;
+    if constexpr (WM * WN <= 8) {
+      if (g.row_half) {
+        tile_epilogue_rowside<DT, NR, MT, BM>(g, acc, M0, N0, wm, wn, lg, li);
+        done = true;
+      }
+    }
+    if (!done) tile_epilogue<DT, NR, MT, BM, (WM * WN <= 8), (WM * WN <= 8)>(g, acc, M0, N0, wm, wn, lg, li, 0u);
   } else {
     bool done = false;
     if constexpr (WM * WN <= 8) {  // (the 16-wave tiles have a 128-register budget: no room for a second epilogue)
@@ -1102,10 +1348,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
 //   B halves of K-tile t+1 are staged in phases 0, 1 of K-tile t (their slots were last read in phase 3 of t-1),
 //   A halves of K-tile t+2 in phase 3 of t (A sub-tiles are read in phases 0 and 2 only), followed by the wait that
 //   retires everything K-tile t+1 needs; the first reads of t+1 come two barriers later in either group.
-template <int DT>
+template <int DT, int EPI = 0>   // EPI 2: + the two halves of a LayerNorm folded into the consumer (tile_row_affine / tile_epilogue_rowside)
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   constexpr int NR = 4, MT = 8, BM = 256, BN = 256, HTB = 16384;  // HTB: bytes of a half-tile
-  __shared__ __attribute__((aligned(16))) uint4 smem[8 * HTB / 16];
+  // (EPI 2: + (mean, rstd) of the 256 rows and the colsum of the 256 columns of a folded LayerNorm)
+  __shared__ __attribute__((aligned(16))) uint4 smem[8 * HTB / 16 + (EPI == 2 ? (2 * BM + BN) / 4 : 0)];
   char* const lds = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1116,6 +1363,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   const int64_t M0 = (int64_t)(L / (unsigned)g.tiles_n) * BM;
   const int N0 = (int)(L % (unsigned)g.tiles_n) * BN;
   const int nkt = g.nkt;  // even (host)
+  [[maybe_unused]] u32x4 rsq[EPI == 2 ? ROW_STAT_LOADS : 1], csq;
+  if constexpr (EPI == 2) row_stats_issue(g, M0, N0, BM, BN, tid, rsq, csq);   // (all out of range without a_row_stats)
 
   auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -1210,6 +1459,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
 
   // ---- prologue: K-tile 0 complete, the A halves of K-tile 1 in flight ----
   stage(0, 0, 0, 0); stage(0, 1, 0, 0); stage(1, 0, 0, 0); stage(1, 1, 0, 0);
+  if constexpr (EPI == 2) {
+    // the statistics were requested before K-tile 0: the compiler's wait for them is the wait for K-tile 0 the first phase
+    // needs anyway; the K loop's barriers order these LDS writes before the epilogue's reads
+    if (g.a_row_stats) {
+      float* mr = reinterpret_cast<float*>(lds + 8 * HTB);
+      row_stats_finish(g, BM, BN, tid, rsq, csq, mr, mr + 2 * BM);
+    }
+  }
   stage(0, 0, 1, 1); stage(0, 1, 1, 1);
   asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   if (wr == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind group 0 from here on
@@ -1249,7 +1506,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   }
   if (wr == 0) asm volatile("s_barrier" ::: "memory");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs must not outlive the block's LDS
-  tile_epilogue<DT, NR, MT, BM, true>(g, acc, M0, N0, wr, wc, lg, li, 0u);
+  if constexpr (EPI == 2) {
+    if (g.a_row_stats) {
+      const float* mr = reinterpret_cast<const float*>(lds + 8 * HTB);
+      tile_row_affine<NR, MT>(acc, wr, wc, lg, li, mr, mr + 2 * BM);
+    }
+    if (g.row_half) tile_epilogue_rowside<DT, NR, MT, BM>(g, acc, M0, N0, wr, wc, lg, li);
+    else tile_epilogue<DT, NR, MT, BM, true, true>(g, acc, M0, N0, wr, wc, lg, li, 0u);
+  } else {
+    tile_epilogue<DT, NR, MT, BM, true>(g, acc, M0, N0, wr, wc, lg, li, 0u);
+  }
 }
 
 // Dense GEMM whose tile holds WHOLE rows at N = 640 (level 1 of the UNets), so that the LayerNorm that follows the projection
@@ -1435,6 +1701,18 @@ extern "C" int mimo_tune_trace(unsigned long long* dst, int n) {
 }
 #endif
 
+// one-block-per-tile launch of gemm_kernel; dense launches that carry a folded LayerNorm half take the EPI = 2 instantiation
+#define MIMO_LAUNCH_GK(WM_, WN_, NS_, MT_, nwg_, thr_)                                                                    \
+  do {                                                                                                                    \
+    if constexpr (MODE == 0) {                                                                                            \
+      if (folded) {                                                                                                       \
+        hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, WM_, WN_, NS_, MT_, 2>), dim3((unsigned)(nwg_)), dim3(thr_), 0, st, g); \
+        break;                                                                                                            \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, WM_, WN_, NS_, MT_>), dim3((unsigned)(nwg_)), dim3(thr_), 0, st, g);      \
+  } while (0)
+
 template <int DT, int MODE, int NR>
 int launch_nr(GemmArgs& g, hipStream_t st) {
 #ifdef MIMO_TUNE
@@ -1463,7 +1741,10 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
   if (tn.tap_inner && MODE != 0) g.flags |= F_TAP_INNER;
   if (cfg == 3 && NR == 5) cfg = 4;  // 16 waves x 128 registers cannot hold a 64 x 80 accumulator tile plus the epilogue
   if (cfg == 3 && g.colstats) cfg = 4;  // the 16-wave tile has no statistics epilogue
-  const bool allow_splitk = tn.splitk && !(g.flags & MIMO_EPI_NO_SPLITK) && !g.colstats && !g.ln_out;
+  const bool folded = g.row_half || g.a_row_stats;   // (plain one-block-per-tile launches only)
+  if (cfg == 3 && g.row_half) cfg = 4;  // the 16-wave tile has no row-statistics epilogue either
+  if (cfg == 2 && folded) cfg = 1;      // the 3-stage ring of the L tile leaves no LDS for the (mean, rstd, colsum) region
+  const bool allow_splitk = tn.splitk && !(g.flags & MIMO_EPI_NO_SPLITK) && !g.colstats && !g.ln_out && !folded;
   // fused LayerNorm output: the tile must hold whole rows (N == 320 = the NR = 5 XL8 width), dense only
   if (g.ln_out) {
     if constexpr (MODE == 0 && NR == 5) {
@@ -1527,25 +1808,25 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
     // persistent blocks pay off (measured +2..7 %) for short reductions over many rounds of tiles — the level-0 linears;
     // with 2-3 exactly filled rounds or long K the plain launch is faster (tools/microbench.py --ab MIMO_GEMM_PERSIST=0)
-    if (MODE == 0 && tn.persist && !g.colstats && bm == 256 && nwg >= 3 * (int64_t)cus && g.nkt >= 2 && g.nkt <= 20) {
+    if (MODE == 0 && tn.persist && !g.colstats && !folded && bm == 256 && nwg >= 3 * (int64_t)cus && g.nkt >= 2 && g.nkt <= 20) {
       g.ntiles = (unsigned)nwg;
       hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 2, 4, 8>), dim3((unsigned)cus), dim3(512), 0, st, g);
       MIMO_LAUNCH_CHECK();
       return MIMO_OK;
     }
-    if (bm == 256) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 8>), dim3((unsigned)nwg), dim3(512), 0, st, g);
-    else if (bm == 192) hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 6>), dim3((unsigned)nwg), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 4, 2, 4>), dim3((unsigned)nwg), dim3(512), 0, st, g);
+    if (bm == 256) MIMO_LAUNCH_GK(2, 4, 2, 8, nwg, 512);
+    else if (bm == 192) MIMO_LAUNCH_GK(2, 4, 2, 6, nwg, 512);
+    else MIMO_LAUNCH_GK(2, 4, 2, 4, nwg, 512);
   } else if (cfg == 3) {
     g.tiles_n = tn_xl;
     const int64_t nwg = m256 * tn_xl;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
     if constexpr (NR == 4) {
-      if (MODE == 0 && tn.persist && nwg >= 3 * (int64_t)cus && g.nkt >= 2) {  // GEGLU: +6 % at every level
+      if (MODE == 0 && tn.persist && !folded && nwg >= 3 * (int64_t)cus && g.nkt >= 2) {  // GEGLU: +6 % at every level
         g.ntiles = (unsigned)nwg;
         hipLaunchKernelGGL((gemm_dense_persist_kernel<DT, NR, 4, 4, 4>), dim3((unsigned)cus), dim3(1024), 0, st, g);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 4, 4, 2, 4>), dim3((unsigned)nwg), dim3(1024), 0, st, g);
+        MIMO_LAUNCH_GK(4, 4, 2, 4, nwg, 1024);
       }
     }
   } else if (cfg == 2) {
@@ -1557,7 +1838,7 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     g.tiles_n = tn_s;
     const int64_t nwg = ((g.M + 127) / 128) * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
-    hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, 2, 2, 2, 4>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    MIMO_LAUNCH_GK(2, 2, 2, 4, nwg, 256);
   }
   (void)geglu;
   MIMO_LAUNCH_CHECK();
@@ -1567,6 +1848,16 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
 // MIMO_GEMM_8P (tune build; the shipped default is the constant below): 1 = dense GEMMs with an even number of K-tiles
 // and enough 256 x 256 tiles take the 8-phase kernel
 constexpr int GEMM_8P_DEFAULT = 1;
+
+// Column-slot width of mimo_epilogue_ext.row_stats = the 16 NR columns one wave owns in the kernel family a producer of
+// width N runs on — chosen from N alone (never from M), so a row's partial sums do not depend on the batch:
+// 64 (gemm8_kernel, or the NR = 4 tiles when the row count is too small for it) where 256-wide tiles fit N, else 80 (NR = 5).
+int row_slot_width(int N) {
+  const int tn8 = (N + 255) / 256;
+  if (tn8 * 256 - N <= N / 12 && N % 64 == 0) return 64;
+  if (N % 160 == 0) return 80;
+  return N % 64 == 0 ? 64 : 0;
+}
 
 template <int DT, int MODE>
 int launch(const GemmArgs& g0, hipStream_t st) {
@@ -1579,11 +1870,13 @@ int launch(const GemmArgs& g0, hipStream_t st) {
     const bool n_fits = tn8 * 256 - g.N <= g.N / 12;
     if (p8 && !g.colstats && !g.ln_out && (g.K % 128) == 0 && n_fits && nt8 >= 128 && nt8 <= 0x7fffffff && g.M < 0x7fffffff) {
       g.tiles_n = (int)tn8;
-      hipLaunchKernelGGL((gemm8_kernel<DT>), dim3((unsigned)nt8), dim3(512), 0, st, g);
+      if (g.row_half || g.a_row_stats) hipLaunchKernelGGL((gemm8_kernel<DT, 2>), dim3((unsigned)nt8), dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((gemm8_kernel<DT>), dim3((unsigned)nt8), dim3(512), 0, st, g);
       MIMO_LAUNCH_CHECK();
       return MIMO_OK;
     }
   }
+  if (g.row_half) return row_slot_width(g.N) == 80 ? launch_nr<DT, MODE, 5>(g, st) : launch_nr<DT, MODE, 4>(g, st);
   // NR = 5 (BN = 160) divides every SD1.5 width (320/640/960/1280/1920/2560); NR = 4 otherwise
   if (!geglu && (g.N % 160 == 0)) return launch_nr<DT, MODE, 5>(g, st);
   return launch_nr<DT, MODE, 4>(g, st);
@@ -1596,7 +1889,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int check_ext(const mimo_epilogue_ext* e, GemmArgs& g, int64_t M, int N, unsigned flags) {
   g.colstats = nullptr; g.ln_gamma = g.ln_beta = g.ln_pe = nullptr; g.ln_out = nullptr;
   g.ln_eps = 0.f; g.ln_rows_per_frame = 1; g.ln_pe_frames = 1;
+  g.row_half = nullptr; g.row_stats = nullptr; g.a_row_stats = nullptr; g.a_colsum = nullptr; g.a_slots = 0; g.a_eps = 0.f;
   if (!e) return MIMO_OK;
+  if (e->row_half || e->row_stats) {   // producer half of a folded LayerNorm: fp32 result + half copy + row statistics
+    if (!e->row_half || !e->row_stats || e->colstats || e->ln_out || !(flags & MIMO_EPI_OUT_F32) ||
+        (flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || row_slot_width(N) == 0 || M >= 0x7fffffffLL / ((int64_t)N * 2) ||
+        !aligned16(e->row_half) || !aligned16(e->row_stats))
+      return MIMO_EINVAL;
+    g.row_half = e->row_half; g.row_stats = e->row_stats;
+  }
+  if (e->a_row_stats || e->a_colsum) {  // consumer half
+    if (!e->a_row_stats || !e->a_colsum || e->a_slots <= 0 || (e->a_slots & 1) || e->a_slots > 2 * ROW_STAT_LOADS || e->colstats || e->ln_out ||
+        M >= 0x7fffffffLL / ((int64_t)e->a_slots * 8) || !aligned16(e->a_row_stats) || !aligned16(e->a_colsum))
+      return MIMO_EINVAL;
+    g.a_row_stats = e->a_row_stats; g.a_colsum = e->a_colsum; g.a_slots = e->a_slots; g.a_eps = e->a_eps;
+  }
   if (e->colstats) {
     if ((M & 31) || (N & 3) || (flags & MIMO_EPI_GEGLU) || !aligned16(e->colstats)) return MIMO_EINVAL;
     g.colstats = e->colstats;
@@ -1642,7 +1949,7 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
 #ifndef MIMO_NO_STREAM
 #define MIMO_NO_STREAM 0
 #endif
-  if (!MIMO_NO_STREAM && tune_env("MIMO_GEMM_STREAM", 1) && mimo_stream::supported(M, N, K, (flags & MIMO_EPI_NO_SPLITK) != 0) && !residual && !img_bias && !g.colstats && !g.ln_out &&
+  if (!MIMO_NO_STREAM && tune_env("MIMO_GEMM_STREAM", 1) && mimo_stream::supported(M, N, K, (flags & MIMO_EPI_NO_SPLITK) != 0) && !residual && !img_bias && !g.colstats && !g.ln_out && !g.row_half && !g.a_row_stats &&
       !(flags & (MIMO_EPI_SILU | MIMO_EPI_OUT_F32)) && out_scale == 1.f && (lda & 7) == 0 && (ldo & 3) == 0 &&
       aligned16(A) && aligned16(W) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {
     mimo_stream::Args a{};
@@ -1678,7 +1985,8 @@ extern "C" int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const
   if ((p->Hup > 0) != (p->Wup > 0)) return MIMO_EINVAL;
   if (flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_RES_F32 | MIMO_EPI_NO_SPLITK)) return MIMO_EINVAL;
   if (!aligned16(in) || !aligned16(W) || !aligned16(out) || (in2 && !aligned16(in2))) return MIMO_EINVAL;
-  if (ext && ext->ln_out) return MIMO_EINVAL;  // the fused LayerNorm output exists for dense GEMMs only
+  if (ext && (ext->ln_out || ext->row_half || ext->row_stats || ext->a_row_stats || ext->a_colsum))
+    return MIMO_EINVAL;  // the LayerNorm side outputs / folded LayerNorm exist for dense GEMMs only
   // thin-input layers (pose guider, VAE conv_in): direct convolution, see thinconv.hip
   if (tune_env("MIMO_THIN_CONV", 1) && !in2 && p->Cin2 == 0 && !img_bias && !residual && !(ext && ext->colstats) && p->Hup == 0 &&
       !(flags & ~(MIMO_EPI_SILU | MIMO_EPI_OUT_F32 | MIMO_EPI_NO_SPLITK))) {
@@ -1732,6 +2040,11 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
                            size_t workspace_bytes, void* stream) {
   return mimo_conv2d_ext(dtype, in, in2, W, out, p, bias, img_bias, residual, out_scale, flags, workspace,
                          workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mimo_row_stat_slots(int N) {
+  const int w = N > 0 ? row_slot_width(N) : 0;
+  return w ? N / w : 0;
 }
 
 extern "C" int mimo_version(void) { return 5; }

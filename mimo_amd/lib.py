@@ -27,7 +27,8 @@ class ConvParams(ctypes.Structure):
 
 class EpilogueExt(ctypes.Structure):  # mimo_epilogue_ext
     _fields_ = [("colstats", c_vp), ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ln_pe", c_vp),
-                ("ln_eps", c_f), ("ln_pe_frames", c_i), ("ln_rows_per_frame", c_i64)]
+                ("ln_eps", c_f), ("ln_pe_frames", c_i), ("ln_rows_per_frame", c_i64),
+                ("row_half", c_vp), ("row_stats", c_vp), ("a_row_stats", c_vp), ("a_colsum", c_vp), ("a_slots", c_i), ("a_eps", c_f)]
 
 
 class HconvParams(ctypes.Structure):  # mimo_hconv_params
@@ -45,6 +46,7 @@ SIGNATURES = {
     "mimo_version": [],
     "mimo_reload_tuning": [],
     "mimo_workspace_bytes": [],
+    "mimo_row_stat_slots": [c_i],
     "mimo_gemm": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u, c_vp,
                   c_sz, c_vp],
     "mimo_gemm_ext": [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i, c_i, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_f, c_u,
@@ -120,6 +122,11 @@ def load():
         fn.restype = RESTYPES.get(name, c_i)
     _lib = lib
     return lib
+
+
+def call_int(name, *args):
+    """Entry points that return a value instead of a status (mimo_row_stat_slots, mimo_version)."""
+    return int(getattr(load(), name)(*args))
 
 
 def call(name, *args):

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .packing import pack_block_head_stream, pack_block_tail_stream, pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail
+from .packing import pack_block_head_stream, pack_block_tail_stream, pack_conv, pack_ff2_kperm, pack_geglu, pack_proj_tail, pack_ln_fold
 
 
 LOG2E = 1.4426950408889634
@@ -305,6 +305,12 @@ class _FeedForward(nn.Module):
         self.net = nn.ModuleList([_GEGLU(dim, 4 * dim), nn.Identity(), nn.Linear(4 * dim, dim)])
 
 
+def _fold_geglu(proj, norm, dt):
+    """packing.pack_ln_fold of a GEGLU projection (GEGLU row packing first) with the LayerNorm in front of it."""
+    w, b = pack_geglu(proj.weight, proj.bias, torch.float32)
+    return pack_ln_fold(w, norm.weight, norm.bias, b, dt)
+
+
 def _ff_fusable(p, n3, out_f32):
     # (batch-invariant runs — split-K off — take the fused kernel whatever the row count: a b = 1 unit and the b = 2 launch
     # of the same window must go through the same kernel, the two forms differ in their fp32 summation order)
@@ -319,7 +325,11 @@ def _ff_run(ctx, p, x_f32, n3, out_f32):
     if _ff_fusable(p, n3, out_f32):
         # C = 320: FF1 + GEGLU + FF2 + residual in ONE launch, the [M, 4C] intermediate stays on the chip (ff_fused.hip)
         return ops.ff_fused(n3, p["ff1_w"], p["ff1_b"], p["ff2_wk"], p["ff2_b"], x_f32)
-    h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
+    if isinstance(n3, ops.LnFold):  # C >= 640: the LayerNorm is folded into this projection (ops.LN_FOLD)
+        f = p["ff1_f"]
+        h = ops.gemm(n3, f["w"], bias=f["bias"], colsum=f["colsum"], geglu=True)
+    else:
+        h = ops.gemm(n3, p["ff1_w"], bias=p["ff1_b"], geglu=True)
     return ops.gemm(h, p["ff2_w"], bias=p["ff2_b"], residual=x_f32, out_f32=out_f32)
 
 
@@ -382,7 +392,11 @@ class SpatialTransformerBlock(HipModule):
             ff2_wk=pack_ff2_kperm(self.ff.net[2].weight, dt) if self.dim == ops.FF_FUSED_DIM else None,
             ff2_b=_f32(self.ff.net[2].bias),
             n1w=_f32(self.norm1.weight), n1b=_f32(self.norm1.bias),
-            n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias))
+            n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias),
+            # C >= 640: norm1 folded into the QKV projection, norm3 into the GEGLU projection (ops.LN_FOLD)
+            qkv_f=pack_ln_fold(self.qkv_weight(), self.norm1.weight, self.norm1.bias, None, dt)
+            if self.dim >= ops.LN_FOLD_MIN_C else None,
+            ff1_f=_fold_geglu(self.ff.net[0].proj, self.norm3, dt) if self.dim >= ops.LN_FOLD_MIN_C else None)
 
     def qkv_weight(self):
         """fp32 [3C, C] = [W_q * softmax_scale * log2(e); W_k; W_v]: the attention kernel exponentiates the MFMA result as is."""
@@ -400,9 +414,10 @@ class SpatialTransformerBlock(HipModule):
         return (wo @ wv).float().to(a2.to_out[0].weight.device), _f32(a2.to_out[0].bias)
 
     def ln1(self, dtype):
-        """norm1 as the `ln=` argument of the GEMM that produces this block's input (fused into its epilogue)."""
+        """norm1 as the `ln=` argument of the GEMM that produces this block's input (fused into its epilogue at C = 320,
+        folded into the QKV projection at C >= 640 — except in write mode, which banks the normalised tensor itself)."""
         p = self.packed(dtype)
-        return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps)
+        return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps, fold=self.mode != "write")
 
     def run(self, ctx, t, n_img, N, out_f32=False, n1=None, proj=None, x=None, qkv=None):
         """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it; qkv = the fused Q/K/V
@@ -419,7 +434,11 @@ class SpatialTransformerBlock(HipModule):
                 self.bank.append(bank if ctx.bank_rows is None else bank[ctx.bank_rows])
                 if ctx.stop_after is self:
                     raise EarlyExit()
-            qkv = ops.gemm(n1, p["qkv"])
+            if isinstance(n1, ops.LnFold):
+                f = p["qkv_f"]
+                qkv = ops.gemm(n1, f["w"], bias=f["bias"], colsum=f["colsum"])
+            else:
+                qkv = ops.gemm(n1, p["qkv"])
         else:
             assert self.mode != "write"
         qkv = qkv.view(n_img, N, 3 * C)
@@ -440,7 +459,7 @@ class SpatialTransformerBlock(HipModule):
         # to_out + collapsed attn2 + residual, with norm3 of the result fused into the same epilogue (C = 320)
         y, n3 = ops.gemm(o.view(-1, C), p["o_w"], bias=p["o_b"], img_bias=ctx.attn2[:, s:e],
                          rows_per_img=ctx.F * N, residual=t, out_f32=True,
-                         ln=dict(gamma=p["n3w"], beta=p["n3b"], eps=self.norm3.eps))
+                         ln=dict(gamma=p["n3w"], beta=p["n3b"], eps=self.norm3.eps, fold=True))
         if proj is not None:
             return _ff_proj_run(ctx, p, y, n3, proj, x, N)
         return _ff_run(ctx, p, y, n3, out_f32)
@@ -577,7 +596,22 @@ class MotionModule(HipModule):
             d[f"o_w{i}"], d[f"o_b{i}"] = h(a.to_out[0].weight), _f32(a.to_out[0].bias)
             d[f"nw{i}"], d[f"nb{i}"] = _f32(nrm.weight), _f32(nrm.bias)
             d[f"pe{i}"] = _f32(a.pos_encoder.pe[0])
+            if self.dim >= ops.LN_FOLD_MIN_C:
+                # norms[i] folded into this QKV projection (ops.LN_FOLD); the positional table, added BEHIND the LayerNorm
+                # (motion_module.py:276-279), becomes a per-frame bias row pe[f] @ W^T of the projection
+                d[f"qkv_f{i}"] = pack_ln_fold(qkv_w, nrm.weight, nrm.bias, None, dt)
+                d[f"pew{i}"] = (a.pos_encoder.pe[0].detach().double() @ qkv_w.double().t()).float().contiguous()
+        if self.dim >= ops.LN_FOLD_MIN_C:
+            d["ff1_f"] = _fold_geglu(blk.ff.net[0].proj, blk.ff_norm, dt)
         return d
+
+    def _pe_bias(self, p, i, b, F):
+        """fp32 [b * F, 3C]: row img = the positional row of frame img % F through the QKV projection (cached per (i, b, F))."""
+        cache = self.__dict__.setdefault("_pe_bias_cache", {})
+        key = (i, b, F, p[f"pew{i}"].data_ptr())
+        if key not in cache:
+            cache[key] = p[f"pew{i}"][:F].repeat(b, 1).contiguous()
+        return cache[key]
 
     def run(self, ctx, x):
         p = self.packed(ctx.dtype)
@@ -605,12 +639,22 @@ class MotionModule(HipModule):
             return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=32, eps=1e-6, silu=False, dtype=ctx.dtype)
         # every LayerNorm (+ positional encoding) rides in the epilogue of the GEMM that produces its input
-        ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], pe=p[f"pe{i}"], rows_per_frame=HW, pe_frames=ctx.F) for i in range(2)]
-        ln.append(dict(gamma=p["fnw"], beta=p["fnb"]))
+        if ops.ln_foldable(C):  # C >= 640: each LayerNorm is folded into the projection that consumes it (ops.LN_FOLD)
+            norms = self.temporal_transformer.transformer_blocks[0].norms
+            ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], eps=norms[i].eps, fold=True) for i in range(2)]
+            ln.append(dict(gamma=p["fnw"], beta=p["fnb"], eps=blk_eps, fold=True))
+        else:
+            ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], pe=p[f"pe{i}"], rows_per_frame=HW, pe_frames=ctx.F) for i in range(2)]
+            ln.append(dict(gamma=p["fnw"], beta=p["fnb"]))
         t, u = ops.gemm(g.view(-1, C), p["pi_w"], bias=p["pi_b"], out_f32=True, ln=ln[0])
         out = None
         for i in range(2):
-            qkv = ops.gemm(u, p[f"qkv{i}"])
+            if isinstance(u, ops.LnFold):
+                f = p[f"qkv_f{i}"]
+                qkv = ops.gemm(u, f["w"], bias=f["bias"], colsum=f["colsum"], img_bias=self._pe_bias(p, i, ctx.b, ctx.F),
+                               rows_per_img=HW)
+            else:
+                qkv = ops.gemm(u, p[f"qkv{i}"])
             o = ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ctx.b, ctx.F, HW, self.heads)
             if i == 1:  # ... + to_out + residual + LayerNorm + feed-forward + proj_out + residual: one launch at C = 320
                 out = _block_tail_run(ctx, p, o, t, p, x.view(-1, C), ("o_b1", "fnw", "fnb"), blk_eps, colstats=HW)

@@ -173,8 +173,11 @@ def stats_of(t):
     return getattr(t, "_cs", None)
 
 
-def _ext(colstats=None, ln_out=None, ln=None):
+def _ext(colstats=None, ln_out=None, ln=None, row_half=None, row_stats=None, a_fold=None, colsum=None):
     e = L.EpilogueExt()
+    e.row_half, e.row_stats = _ptr(row_half), _ptr(row_stats)
+    if a_fold is not None:
+        e.a_row_stats, e.a_colsum, e.a_slots, e.a_eps = a_fold.stats.data_ptr(), colsum.data_ptr(), a_fold.stats.shape[1], a_fold.eps
     e.colstats = _ptr(colstats)
     e.ln_out = _ptr(ln_out)
     if ln is not None:
@@ -204,14 +207,55 @@ def _is_f32(t):
 LN_OUT_640 = False
 
 
+# LayerNorm folded into the projection that consumes it, where no tile holds a whole row (C = 640 / 1280: levels 1-3): the
+# producer GEMM leaves a half copy of its rows and per-row partial sums (mimo_epilogue_ext row_half / row_stats), the consumer
+# multiplies the raw rows by gamma o W and applies mean / rstd in its epilogue.  The normalised tensor is never written and
+# the fp32 tensor never re-read: the layer_norm launch and 4 of its 6 bytes per element disappear.  A property of the layer
+# width only (never of the batch).  Numerics: the rounded tensor is the LayerNorm's input instead of its output — priced on
+# the oracle as class LNRAW (oracle/error_budget.py): 2.25e-4 against 2.62e-4 for LN at step 3 of configs[0].
+LN_FOLD = True
+LN_FOLD_MIN_C = 640
+
+
+class LnFold:
+    """The un-normalised operand of a folded LayerNorm: half rows + per-row (sum, sum of squares) partials, eps."""
+
+    def __init__(self, xh, stats, eps):
+        self.xh, self.stats, self.eps = xh, stats, float(eps)
+
+    @property
+    def shape(self):
+        return self.xh.shape
+
+
+_SLOTS = {}
+
+
+def row_stat_slots(N):
+    if N not in _SLOTS:
+        _SLOTS[N] = L.call_int("mimo_row_stat_slots", N)
+    return _SLOTS[N]
+
+
+def ln_foldable(N):
+    return LN_FOLD and N >= LN_FOLD_MIN_C and row_stat_slots(N) > 0 and row_stat_slots(N) % 2 == 0
+
+
 def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f32=False, silu=False,
-         geglu=False, out=None, out_scale=1.0, colstats=False, ln=None):
+         geglu=False, out=None, out_scale=1.0, colstats=False, ln=None, colsum=None):
     """out[M, N] = epilogue(a[M, K] @ w[N, K]^T); a may be a row-strided view (last stride 1).
 
     colstats=<rows per image>: also emit GroupNorm column statistics of `out` (attached as out._cs) when the image size
     allows (see COLSTATS_MIN_HW).
     ln=dict(gamma, beta[, eps, pe, rows_per_frame, pe_frames]): also return LayerNorm(out) (+ pe) as a half tensor —
-    fused into the epilogue when N == 320 or 640, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out)."""
+    fused into the epilogue when N == 320 or 640, otherwise a separate mimo_layer_norm launch.  Returns (out, ln_out).
+    ln=dict(..., fold=True) with ln_foldable(N): nothing is normalised here; returns (out, LnFold) for a consumer called as
+    gemm(LnFold, packing.pack_ln_fold(...)["w"], bias=[...]["bias"], colsum=[...]["colsum"], ...) (a positional table, if any,
+    is the consumer's per-image bias)."""
+    a_fold = None
+    if isinstance(a, LnFold):
+        assert colsum is not None and colsum.dtype == torch.float32 and colsum.shape == (w.shape[0],)
+        a_fold, a = a, a.xh
     _chk(a, "a")
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous()
     assert a.dtype == w.dtype
@@ -239,16 +283,28 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     fuse_ln = (ln is not None and (N == 320 or (N == 640 and LN_OUT_640 and K % 32 == 0)) and not geglu and not silu
                and out.stride(0) == N and out.is_contiguous() and (residual is None or ldr == N)
                and (ln.get("pe") is None or (ln.get("rows_per_frame", 0) % 128 == 0 and ln.get("pe_frames", 0) > 0)))
-    cs = ln_out = None
-    if not fuse_ln and not geglu and N % 4 == 0 and _want_colstats(colstats, M):
+    fold = (ln is not None and ln.get("fold") and not fuse_ln and ln_foldable(N) and out.dtype == torch.float32 and not geglu
+            and not silu and ln.get("pe") is None)
+    cs = ln_out = row_half = row_stats = None
+    if fold:
+        row_half = torch.empty((M, N), device=a.device, dtype=a.dtype)
+        row_stats = torch.empty((M, row_stat_slots(N), 2), device=a.device, dtype=torch.float32)
+    if not fuse_ln and not fold and a_fold is None and not geglu and N % 4 == 0 and _want_colstats(colstats, M):
         cs = torch.empty((M // 32, 2, N), device=a.device, dtype=torch.float32)
     if fuse_ln:
         ln_out = torch.empty((M, N), device=a.device, dtype=a.dtype)
     _count(2 * M * N * K)
-    with _Bracket("gemm_kernel", 2 * M * N * K, M * K * a.element_size() + _nbytes(w, out, residual, ln_out, cs),
-                  f"gemm M{M} N{N} K{K}{' geglu' if geglu else ''}{' ln' if fuse_ln else ''}{' f32' if out_f32 else ''}"):
+    with _Bracket("gemm_kernel", 2 * M * N * K, M * K * a.element_size() + _nbytes(w, out, residual, ln_out, cs, row_half, row_stats)
+                  + (a_fold.stats.numel() * 4 if a_fold is not None else 0),
+                  f"gemm M{M} N{N} K{K}{' geglu' if geglu else ''}{' ln' if fuse_ln else ''}{' f32' if out_f32 else ''}"
+                  f"{' rows' if fold else ''}{' folded' if a_fold is not None else ''}"):
         ws = _workspace(a.device)
-        if cs is None and ln_out is None:
+        if fold or a_fold is not None:
+            ext = _ext(row_half=row_half, row_stats=row_stats, a_fold=a_fold, colsum=colsum)
+            L.call("mimo_gemm_ext", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
+                   out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
+                   float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, ctypes.byref(ext), _stream())
+        elif cs is None and ln_out is None:
             L.call("mimo_gemm", dt_code(a.dtype), a.data_ptr(), a.stride(0), w.data_ptr(), out.data_ptr(),
                    out.stride(0), M, N, K, _ptr(bias), _ptr(img_bias), ldib, rows_per_img, _ptr(residual), ldr,
                    float(out_scale), flags, ws.data_ptr(), ws.numel() * 4, _stream())
@@ -260,6 +316,8 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     with_stats(out, cs)
     if ln is None:
         return out
+    if fold:
+        return out, LnFold(row_half, row_stats, ln.get("eps", 1e-5))
     if ln_out is None:
         ln_out = layer_norm(out, ln["gamma"], ln["beta"], eps=ln.get("eps", 1e-5), dtype=a.dtype, pe=ln.get("pe"),
                             rows_per_frame=ln.get("rows_per_frame", 0), pe_frames=ln.get("pe_frames", 0))

@@ -54,6 +54,21 @@ def pack_geglu(weight, bias, dtype):
     return wp.to(dtype).contiguous(), bp.contiguous()
 
 
+def pack_ln_fold(weight, gamma, beta, bias, dtype):
+    """LayerNorm folded into the projection that consumes it (mimo_epilogue_ext a_row_stats / a_colsum; C = 640 / 1280):
+        LayerNorm(x) @ W^T + b = rstd * (x @ (gamma o W)^T - mean * colsum) + (W @ beta + b)
+    weight: fp32-convertible [N, K] in the row order the consuming kernel expects (for GEGLU: pack_geglu's fp32 output and its
+    packed bias).  Returns dict(w = (gamma o W) in `dtype`, colsum = fp32 [N] row sums of that ROUNDED weight — the centring is
+    then exact for what the MFMAs sum —, bias = fp32 [N] = W @ beta + b)."""
+    w = weight.detach().double()
+    g, be = gamma.detach().double(), beta.detach().double()
+    wf = (w * g[None, :]).float().to(dtype).contiguous()
+    c2 = w @ be
+    if bias is not None:
+        c2 = c2 + bias.detach().double()
+    return dict(w=wf, colsum=wf.double().sum(1).float().contiguous(), bias=c2.float().contiguous())
+
+
 def ff2_kperm():
     """Position p = 8 g + j of a 32-wide K block holds original index 4 g + j (j < 4) | 16 + 4 g + (j - 4) (j >= 4): the order
     in which the lanes of an MFMA result tile pair hold a 32-column chunk (lane group g: columns 4g..4g+3 of each 16-tile)."""

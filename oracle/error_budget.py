@@ -13,6 +13,9 @@ Classes:  W weights of every Linear / conv of both UNets | CONV inputs of the 3x
           LN inputs of to_q/to_k/to_v, FF1 and proj_in (LayerNorm / GroupNorm outputs) | QKV outputs of to_q/to_k/to_v
           ATT inputs of to_out (attention outputs) | H inputs of FF2 (GEGLU outputs) | Z inputs of proj_out (FF outputs)
           P softmax probabilities before P.V
+          LNRAW (round 5) what LN becomes if the C >= 640 LayerNorms are folded into their consumer GEMMs (operand = the raw
+          stream rounded to fp16, mean / rstd applied in the epilogue): LN at C = 320 and behind GroupNorm, the LayerNorm INPUT
+          rounded at C >= 640.  Compare with LN alone.
           RES (round 5) the residual stream itself: every tensor the product keeps in fp32 BETWEEN kernels (conv_in + pose,
           conv1 + time embedding, ResBlock sums, proj_in outputs, every attention / feed-forward residual sum, proj_out + res,
           sampler outputs) rounded to fp16 at every write, fp32 arithmetic inside.  Not part of 'all' (= the shipped policy);
@@ -56,6 +59,11 @@ def hooks_for(cls, nets):
                 hs.append(m.register_forward_pre_hook(pre))
             elif cls == "LN" and (leaf in ("to_q", "to_k", "to_v", "proj_in") or parent.endswith("net.0.proj")):
                 hs.append(m.register_forward_pre_hook(pre))
+            elif cls == "LNRAW" and (leaf in ("to_q", "to_k", "to_v", "proj_in") or parent.endswith("net.0.proj")):
+                # the operand stays a LayerNorm OUTPUT only where the product keeps the LayerNorm (C = 320: fused head / tail)
+                # and behind GroupNorm (proj_in); at C >= 640 the rounded tensor is the LayerNorm's INPUT (hooked below)
+                if leaf == "proj_in" or m.in_features == 320:
+                    hs.append(m.register_forward_pre_hook(pre))
             elif cls == "QKV" and leaf in ("to_q", "to_k", "to_v"):
                 hs.append(m.register_forward_hook(post))
             elif cls == "ATT" and parent.endswith("to_out.0"):
@@ -64,6 +72,10 @@ def hooks_for(cls, nets):
                 hs.append(m.register_forward_pre_hook(pre))
             elif cls == "Z" and leaf == "proj_out":
                 hs.append(m.register_forward_pre_hook(pre))
+        if cls == "LNRAW":
+            for m in net.modules():
+                if isinstance(m, nn.LayerNorm) and m.normalized_shape[0] >= 640:
+                    hs.append(m.register_forward_pre_hook(pre))
     return hs
 
 

@@ -845,3 +845,28 @@ def test_statistics_side_outputs_are_decided_by_the_image_size_only():
     assert ops._tail_colstats(4096, 4096 * 48, 320, dev).shape == (4096 * 48 // 32, 2, 320)
     assert ops._tail_colstats(100, 4800, 320, dev) is None      # slabs of 32 rows would straddle images
     assert ops._tail_colstats(False, 4096, 320, dev) is None
+
+
+def test_pack_ln_fold_is_the_layer_norm_followed_by_the_projection():
+    """packing.pack_ln_fold (LayerNorm folded into its consumer, C >= 640): rstd * (x @ W'^T - mean * colsum) + bias equals
+    LayerNorm(x) @ W^T + b, in fp64 to 1e-12 when nothing is rounded; colsum is the row sum of the ROUNDED weight."""
+    from mimo_amd.packing import pack_ln_fold
+    g = torch.Generator().manual_seed(5)
+    C, N, M = 640, 96, 33
+    x = torch.randn(M, C, generator=g, dtype=torch.float64) * 3 + 0.7
+    w = torch.randn(N, C, generator=g, dtype=torch.float64) * C ** -0.5
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    gamma, beta = torch.randn(C, generator=g, dtype=torch.float64) * 0.1 + 1, torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    f = pack_ln_fold(w, gamma, beta, b, torch.float64)
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    got = rstd * (x @ f["w"].t() - mean * f["colsum"].double()[None, :]) + f["bias"].double()[None, :]
+    ref = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) @ w.t() + b
+    assert float((got - ref).abs().max()) < 1e-5   # colsum / bias are stored in fp32
+    h = pack_ln_fold(w, gamma, beta, None, torch.float16)
+    assert h["w"].dtype == torch.float16 and torch.allclose(h["colsum"].double(), h["w"].double().sum(1), atol=1e-6)
+
+
+def test_row_stat_slots_is_a_function_of_the_width_only():
+    from mimo_amd import lib as L
+    assert [L.call_int("mimo_row_stat_slots", n) for n in (320, 640, 1280, 960, 100, 0)] == [4, 8, 20, 15, 0, 0]

@@ -2,6 +2,7 @@
 reference of the same op, on identical half-rounded inputs.  Tolerances are rel-L2 and written
 per test: fp32-out kernels only differ by accumulation order; half-out kernels add one rounding
 (fp16 eps 4.9e-4, bf16 eps 3.9e-3)."""
+import ctypes
 import math
 
 import pytest
@@ -671,6 +672,112 @@ def test_gemm_fused_layer_norm_output_n640(dev, dtype, M, K, with_res, with_pe, 
         finally:
             ops.LN_OUT_640 = False
         assert torch.equal(o2, out[:half]) and torch.equal(y2, y[:half])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,Nout,geglu,with_res,with_ib,with_pe", [
+    (8192, 1280, 3840, False, True, False, False),      # producer and consumer on the 8-phase kernel (64-column slots)
+    (8192 + 77, 640, 1920, False, True, True, False),   # 80-column slots, ragged M, per-image bias in the producer
+    (4096, 640, 5120, True, False, False, False),       # GEGLU consumer
+    (1024, 1280, 3840, False, True, False, True),       # few rows: tiled producer (NR = 4) and consumer; positional table
+    (8192, 640, 1920, False, True, False, True),        # positional table through the 8-phase consumer (paired stores)
+    (200, 1280, 10240, True, True, False, False),
+])
+def test_gemm_layer_norm_folded_into_consumer(dev, dtype, M, C, Nout, geglu, with_res, with_ib, with_pe):
+    """C = 640 / 1280 (no tile holds a row): the LayerNorm between two GEMMs is folded into the second one — the producer leaves
+    half rows + per-row partial sums (mimo_epilogue_ext row_half / row_stats), the consumer multiplies the raw rows by gamma o W
+    and applies mean / rstd in its epilogue (a_row_stats / a_colsum).  Against torch fp32, against the unfolded launches, and
+    bit-identical rows whatever launch (row count, hence tile height / kernel) computes them."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_geglu, pack_ln_fold
+    K, HW, Fr = 640, 128, 4
+    TOL = 1.8 * OUT_TOL[dtype]   # three independent roundings against the fp32 reference: operand, weight, output
+    a = rnd((M, K), dev, dtype, 1)
+    w = rnd((C, K), dev, dtype, 2, K ** -0.5)
+    b = rnd((C,), dev, torch.float32, 3)
+    res = rnd((M, C), dev, torch.float32, 4) * 1.5 + 0.3 if with_res else None
+    g = rnd((C,), dev, torch.float32, 5) * 0.1 + 1
+    be = rnd((C,), dev, torch.float32, 6) * 0.1
+    rpi = 1000
+    ib = rnd(((M + rpi - 1) // rpi, C), dev, torch.float32, 8) if with_ib else None
+    w2 = rnd((Nout, C), dev, torch.float32, 9, C ** -0.5)
+    b2 = rnd((Nout,), dev, torch.float32, 10) * 0.2
+    pe = rnd((Fr, C), dev, torch.float32, 11) * 0.5 if with_pe else None
+    kw = dict(bias=b, residual=res, out_f32=True, img_bias=ib, rows_per_img=rpi if with_ib else 0)
+    assert ops.ln_foldable(C)
+    out, u = ops.gemm(a, w, ln=dict(gamma=g, beta=be, eps=1e-5, fold=True), **kw)
+    assert isinstance(u, ops.LnFold) and u.xh.dtype == dtype and u.stats.shape == (M, ops.row_stat_slots(C), 2)
+    ref_out = a.float() @ w.float().t() + b + (res if with_res else 0)
+    if with_ib:
+        ref_out = ref_out + ib[torch.arange(M, device=dev) // rpi]
+    assert rel_l2(out, ref_out) < ACC_TOL
+    # the side outputs: the stored rows rounded once, and their sums
+    assert torch.equal(u.xh, out.to(dtype))
+    xs = u.xh.double()
+    assert rel_l2(u.stats[..., 0].double().sum(1), xs.sum(1)) < 1e-5 and rel_l2(u.stats[..., 1].double().sum(1), (xs * xs).sum(1)) < 1e-5
+    # the plain launch stores the same fp32 rows
+    ops.LN_FOLD = False
+    try:
+        out_u, y_u = ops.gemm(a, w, ln=dict(gamma=g, beta=be, eps=1e-5), **kw)
+    finally:
+        ops.LN_FOLD = True
+    assert torch.equal(out, out_u)
+    # consumer
+    if geglu:
+        w2p32, b2p = pack_geglu(w2, b2, torch.float32)
+        f = pack_ln_fold(w2p32, g, be, b2p, dtype)
+        w2u, b2u = pack_geglu(w2, b2, dtype)
+    else:
+        f = pack_ln_fold(w2, g, be, b2, dtype)
+        w2u, b2u = w2.to(dtype).contiguous(), b2
+    ckw = {}
+    if with_pe:  # the table is added BEHIND the LayerNorm: through the projection it is a per-image bias row
+        pew = (pe.double() @ w2.double().t()).float()
+        ckw = dict(img_bias=pew[(torch.arange(M // HW, device=dev)) % Fr].contiguous(), rows_per_img=HW)
+    z = ops.gemm(u, f["w"], bias=f["bias"], colsum=f["colsum"], geglu=geglu, **ckw)
+    n = F.layer_norm(ref_out, (C,), g, be, 1e-5)
+    if with_pe:
+        n = n + pe[(torch.arange(M, device=dev) // HW) % Fr]
+    h = n @ w2.t() + b2
+    ref = h[:, :Nout // 2] * F.gelu(h[:, Nout // 2:]) if geglu else h
+    assert z.dtype == dtype and rel_l2(z.float(), ref) < TOL
+    for sl in (slice(0, 1), slice(M - 1, M), slice(M // 2, M // 2 + 1)):
+        assert rel_l2(z[sl].float(), ref[sl]) < 2 * TOL
+    # the unfolded launches: LayerNorm output (+ table) rounded, then the projection
+    yu = y_u if not with_pe else (y_u.float() + pe[(torch.arange(M, device=dev) // HW) % Fr]).to(dtype)
+    z_u = ops.gemm(yu, w2u, bias=b2u, geglu=geglu)
+    assert rel_l2(z_u.float(), ref) < TOL and rel_l2(z.float(), z_u.float()) < 2 * TOL
+    # a row's bits do not depend on the launch it is computed in (fewer rows: another tile height / kernel of the same family)
+    half = 256 if M > 256 else 64
+    o2, u2 = ops.gemm(a[:half].contiguous(), w, ln=dict(gamma=g, beta=be, eps=1e-5, fold=True), bias=b,
+                      residual=None if res is None else res[:half].contiguous(), out_f32=True,
+                      img_bias=ib, rows_per_img=rpi if with_ib else 0)
+    assert torch.equal(o2, out[:half]) and torch.equal(u2.xh, u.xh[:half]) and torch.equal(u2.stats, u.stats[:half])
+    z2 = ops.gemm(u2, f["w"], bias=f["bias"], colsum=f["colsum"], geglu=geglu,
+                  **({k: (v[:half // HW].contiguous() if k == "img_bias" else v) for k, v in ckw.items()}))
+    assert torch.equal(z2, z[:half])
+
+
+def test_gemm_folded_layer_norm_rejects_what_it_does_not_cover(dev):
+    from mimo_amd import lib as L, ops
+    dtype = torch.float16
+    a, w = rnd((256, 640), dev, dtype, 1), rnd((640, 640), dev, dtype, 2)
+    assert ops.row_stat_slots(640) == 8 and ops.row_stat_slots(1280) == 20 and ops.row_stat_slots(100) == 0
+    # half output, GEGLU / SiLU producers and convolutions have no row-statistics epilogue
+    out = torch.empty((256, 640), device=dev, dtype=dtype)
+    xh, st = torch.empty((256, 640), device=dev, dtype=dtype), torch.empty((256, 8, 2), device=dev)
+    ext = ops._ext(row_half=xh, row_stats=st)
+    ws = ops._workspace(dev)
+    with pytest.raises(L.MimoHipError):
+        L.call("mimo_gemm_ext", 0, a.data_ptr(), 640, w.data_ptr(), out.data_ptr(), 640, 256, 640, 640, None, None, 0, 0, None, 0,
+               1.0, 0, ws.data_ptr(), ws.numel() * 4, ctypes.byref(ext), None)
+    # a consumer needs both the statistics and the column sums, and an even slot count
+    o32 = torch.empty((256, 640), device=dev)
+    bad = L.EpilogueExt()
+    bad.a_row_stats, bad.a_slots = st.data_ptr(), 8
+    with pytest.raises(L.MimoHipError):
+        L.call("mimo_gemm_ext", 0, a.data_ptr(), 640, w.data_ptr(), o32.data_ptr(), 640, 256, 640, 640, None, None, 0, 0, None, 0,
+               1.0, L.EPI_OUT_F32, ws.data_ptr(), ws.numel() * 4, ctypes.byref(bad), None)
 
 
 def sdpa_ref(q, k, v, heads):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--mfma-rate", type=float, default=None, help="PFLOP/s to price the MFMA-bound launches at (default 1.3)")
     ap.add_argument("--attn-rate", type=float, default=None, help="PFLOP/s to price spatial attention at (default 1.0)")
+    ap.add_argument("--launches", action="store_true", help="also list every bracketed launch in issue order")
     a = ap.parse_args()
     global MFMA_RATE, ATTN_RATE
     if a.mfma_rate:
@@ -84,6 +85,12 @@ def main():
     print(f"{'shape':64s} {'n':>3s} {'ms':>7s} {'bound':>7s} {'excess':>7s} {'TFLOP/s':>8s} {'TB/s':>6s}")
     for tag, (cnt, ms, bd, fl, nb) in sorted(shapes.items(), key=lambda kv: kv[1][2] - kv[1][1]):
         print(f"{tag:64s} {cnt:3d} {ms:7.2f} {bd:7.2f} {ms - bd:7.2f} {fl / ms / 1e9:8.0f} {nb / ms / 1e9:6.2f}")
+    if a.launches:
+        print("# launches in issue order (tag, us, bound us, TFLOP/s, TB/s)")
+        for (n, e0, e1, fl, nb), tag in zip(ev, tags):
+            ms = e0.elapsed_time(e1)
+            bd = (fl / (ATTN_RATE if n == "attn_kernel" else MFMA_RATE)) if n == "attn_kernel" else max(fl / MFMA_RATE, nb / HBM_RATE)
+            print(f"{tag:64s} {ms*1e3:8.1f} {bd*1e6:8.1f} {fl / ms / 1e9:8.0f} {nb / ms / 1e9:6.2f}")
     reader.clear()
     writer.clear()
 
