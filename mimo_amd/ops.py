@@ -203,7 +203,8 @@ def _is_f32(t):
 
 # The LayerNorm after an N = 640 projection in the GEMM's epilogue (gemm_ln640_kernel: 64 x 640 whole-row tiles).  OFF: measured
 # SLOWER than GEMM + LayerNorm launch (166.6 vs 125.3 us at M49152 K640, 391.6 vs 222.5 at K2560, profiles/r5_ln640_bench.txt) —
-# a 64-row block streams the whole 640 x K weight through LDS-DMA, which fills at ~12 B/clk per CU.  Kept for the record and tested.
+# one block per CU, 20 serial K-tile steps and a 246 KB store epilogue that overlaps with nothing (the LDS-DMA path itself is not the
+# limit: 55-64 B/clk per CU, profiles/r5_lds_fill_probe.txt).  Kept for the record and tested; levels 1-3 use LN_FOLD below instead.
 LN_OUT_640 = False
 
 
