@@ -7,7 +7,7 @@
 with MFMA_RATE = 1.3 PFLOP/s (what the long-K convolutions of this code base sustain at the power-limited clock),
 HBM_RATE = 4.4 TB/s (a plain read-modify-write on this part, profiles/r2_epilogue_io_probe.txt) and ATTN_RATE = 1.0 PFLOP/s
 (d = 40 pads Q.K^T to K = 48 and O^T to 48 rows: 83 % of the 1.2 PFLOP/s the guide quotes for d = 128).
-  python tools/forward_bound.py [--size 512]"""
+  python tools/forward_bound.py [--size 512] [--mfma-rate 1.3] [--attn-rate 1.0] [--launches]   (--launches: every bracketed launch in issue order)"""
 import argparse
 import os
 import sys

@@ -23,6 +23,7 @@
 #   envtests:<ENV=..>;<expr>    pytest -k <expr> on the tune library with environment knobs set
 #   emulate8         bench.py --emulate-world 8 (per-rank schedule of the 8-GPU long-clip job measured on one GPU)
 #   ceiling          tools/ceiling.py (MFMA-only probe + best-case 8192^3 GEMMs)
+#   fillprobe        tools/_ab/lds_fill_probe (build it first: see tools/probes/lds_fill_probe.hip) -> lds_fill_probe.txt
 #   bound:<args>     tools/forward_bound.py --size 512 <args> (e.g. "bound:--mfma-rate 1.25 --attn-rate 1.0")
 #   sh:<command>     any shell command (output -> sh_<n>.txt)
 #   fftrace:<modes>  tools/ff_trace.py <modes> (phase trace + ablations of the fused tail / head, tune library)
@@ -70,6 +71,7 @@ for stage in "$@"; do
     attn_ab:*) timeout 300 python tools/attn_only.py --time ${stage#attn_ab:} 2>&1 | grep -v amdgpu.ids > $O/attn_ab_$n.txt; cat $O/attn_ab_$n.txt ;;
     envtests:*) (IFS=';' read -r ENVS EXPR <<< "${stage#envtests:}"; env MIMO_HIP_LIB=$R/mimo_amd/libmimo_hip_tune.so $ENVS timeout 900 python -m pytest tests -m gpu -q -k "$EXPR" 2>&1 | tail -8) > $O/pytest_env_$n.txt; tail -3 $O/pytest_env_$n.txt ;;
     emulate8) (timeout 600 python bench.py --emulate-world 8 > $O/bench_emulate_world8.json 2> $O/bench_emulate_world8.err); head -c 3000 $O/bench_emulate_world8.json ;;
+    fillprobe) timeout 200 tools/_ab/lds_fill_probe > $O/lds_fill_probe.txt 2>&1; cat $O/lds_fill_probe.txt ;;
     ceiling) timeout 400 python tools/ceiling.py 2>&1 | grep -v amdgpu.ids > $O/mfma_ceiling.txt; cat $O/mfma_ceiling.txt ;;
     bound:*) timeout 400 python tools/forward_bound.py --size 512 ${stage#bound:} 2>&1 | grep -v amdgpu.ids > $O/forward_bound_$n.txt; head -8 $O/forward_bound_$n.txt ;;
     sh:*) (timeout 900 bash -c "${stage#sh:}" 2>&1 | grep -v amdgpu.ids) > $O/sh_$n.txt; cat $O/sh_$n.txt ;;
