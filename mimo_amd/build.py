@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 LIB_PATH = os.path.join(ROOT, "libmimo_hip.so")
-SOURCES = ["gemm_conv.hip", "hconv.hip", "thinconv.hip", "gemm_stream.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip", "image.hip"]
+SOURCES = ["gemm_conv.hip", "hconv.hip", "thinconv.hip", "gemm_stream.hip", "ff_fused.hip", "ff_tail4.hip", "attention.hip", "norm.hip", "elementwise.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+# ff_tail4.hip: one wave per SIMD — packed fp32 VALU (what the SLP vectoriser makes of adjacent scalar adds / fmas) is slow
+# beside MFMAs (MI355X_MICROARCH.md), the GEGLU there is written in scalar operations and must stay scalar
+EXTRA_FLAGS = {"ff_tail4.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
 
 
 def _stale(target, deps):
@@ -36,7 +39,7 @@ def build(force: bool = False, verbose: bool = False, tune: bool = False) -> str
     os.makedirs(objdir, exist_ok=True)
     flags = FLAGS + (["-DMIMO_TUNE"] if tune else [])
     lib_path = TUNE_LIB_PATH if tune else LIB_PATH
-    headers = [os.path.join(CSRC, h) for h in ("common.hip.h", "gemm_stream.hip.h", "thinconv.hip.h")] + [os.path.join(INCLUDE, "mimo_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.hip.h", "gemm_stream.hip.h", "thinconv.hip.h", "ff_fused.hip.h")] + [os.path.join(INCLUDE, "mimo_hip.h")]
     jobs = []
     objs = []
     for s in SOURCES:
@@ -44,7 +47,7 @@ def build(force: bool = False, verbose: bool = False, tune: bool = False) -> str
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

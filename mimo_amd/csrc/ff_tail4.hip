@@ -1,0 +1,537 @@
+// ff_tail4.hip — the fused tail of a C = 320 transformer block (ff_fused.hip, MODE 0 and MODE 2) on FOUR waves, one per SIMD,
+// each with the whole 512-entry register file (gfx950).  Same entry points, same packed weights, same arithmetic in the same
+// order as ff_fused_kernel — the outputs are bit-identical — but a different machine mapping:
+//
+//   ff_fused_kernel (8 waves x 256 registers): the two waves of a SIMD share 32 rows and split the 320 columns; every hidden
+//   chunk, every LayerNorm statistic and every re-used accumulator tile crosses between them through LDS behind barriers, and
+//   the measured step (5 070 cycles per 128 rows and 32 hidden columns, r5_block_head_phase_trace / NOTEBOOK round 5 §7, §11)
+//   is MFMA time PLUS the GEGLU's VALU time PLUS DMA issue: the matrix pipe and the VALU of a SIMD do not overlap across waves
+//   (r5_mfma_ceiling.txt, last table).
+//
+//   ff4_kernel (this file): wave w owns rows [32 w, 32 w + 32) of the 128-row panel and ALL 320 columns: 160 accumulator
+//   registers (the compiler places them in AGPRs) + 80 operand registers + 32 FF1 accumulators.  Nothing is exchanged: the
+//   GEGLU chunk, the LayerNorm operand and the projection operand go from accumulator to MFMA operand inside the wave.  Every
+//   W fragment read from LDS feeds two MFMAs of the same wave as before, but is read by 4 waves instead of 8.  The only
+//   overlap a single wave has is VALU / LDS / DMA issue in the shadow of its OWN MFMAs (about two issue slots per 16-cycle
+//   MFMA, MI355X_MICROARCH.md "one wave per SIMD"), so the feed-forward is software-pipelined by hand:
+//       step j:   FF1(j, value/gate pair 0)  |  FF1(j, pair 1)  |  FF2(j - 1)          <- 120 MFMAs, back to back
+//                 GEGLU(j - 1, pair 1, rows 16..31)  GEGLU(j, pair 0)  GEGLU(j, pair 1, rows 0..15)   <- VALU in their shadow
+//   (in fenced SEGMENTS of four MFMAs with one stage of the GEGLU polynomial each, W fragments fetched two segments ahead),
+//   and the 15 LDS-DMA pieces a wave issues per step are spread over the first 20 segments instead of going out in one burst.
+//
+// Stream protocol (positions, 2-deep ring, one barrier per position, W2 slice one position behind its W1 tile) is the one of
+// ff_fused.hip; the weight tensors are the ones mimo_amd.packing already makes.
+#include "ff_fused.hip.h"
+
+namespace {
+
+constexpr int LDS4_BYTES = XCH_OFF;   // two weight stages + the bias image (no exchange buffers)
+
+// compile-time loop: f(ICf<I>{}) for I in [A, B) — every register-array index below is a constant expression
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (A < B) {
+    f(ICf<A>{});
+    static_for<A + 1, B>(f);
+  }
+}
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
+  static_assert(MODE == 0 || MODE == 2, "feed-forward only | whole block tail");
+  constexpr bool TAIL = MODE == 2;
+  constexpr int NPRE = TAIL ? NTAIL : 0;
+  constexpr int NPOS = NPRE + NSTEP + (TAIL ? NTAIL : 0);
+  __shared__ __attribute__((aligned(16))) uint4 smem[LDS4_BYTES / 16];  // ONE LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned pr = __builtin_amdgcn_readfirstlane((unsigned)tid >> 6);   // row group: rows [32 pr, 32 pr + 32) of the panel
+  const int lg = lane >> 4, li = lane & 15;
+  const unsigned npanels = (unsigned)((g.M + BM - 1) / BM);
+  const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)&smem[0];
+  float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(&smem[0]) + BIAS_OFF);
+  for (int n = tid; n < 8 * C; n += 256) bias_lds[n] = g.b1 ? g.b1[n] : 0.f;
+  for (int n = tid; n < C; n += 256) {
+    bias_lds[8 * C + n] = g.b2 ? g.b2[n] : 0.f;
+    bias_lds[9 * C + n] = (TAIL && g.bp) ? g.bp[n] : 0.f;
+    bias_lds[10 * C + n] = (TAIL && g.bo) ? g.bo[n] : 0.f;
+    bias_lds[11 * C + n] = TAIL ? g.ln_gamma[n] : 0.f;
+    bias_lds[12 * C + n] = TAIL ? g.ln_beta[n] : 0.f;
+  }
+
+  auto make_rsrc = [](const void* ptr, unsigned bytes) -> i32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    i32x4 r;
+    r.x = (int)(uint32_t)a; r.y = (int)((uint32_t)(a >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+  };
+  const i32x4 rW1 = make_rsrc(g.W1, (unsigned)(TAIL ? NPOS * 64 : 8 * C) * (unsigned)ROWB1);
+  const i32x4 rW2 = make_rsrc(g.W2, (unsigned)C * (unsigned)(HID * 2));
+  constexpr unsigned OOBA = 0x80000000u;
+
+  // ---- W stream: the LDS images and the piece -> lane mapping of ff_fused.hip (pieces of 1 KB: 0..39 the W1 tile, 40..59 the
+  // W2 slice); wave w moves W1 pieces w, w + 4, ... (10) and W2 pieces w, w + 4, ... (5) of every position ----
+  const unsigned w1_lane = ((unsigned)lane >> 3) * (unsigned)ROWB1 + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 3) & 7u)) << 4);
+  const unsigned w2_lane = ((unsigned)lane >> 2) * (unsigned)(HID * 2) + ((((unsigned)lane & 3u) ^ (2u * (((unsigned)lane >> 5) & 1u))) << 4);
+  auto dma = [&](const i32x4& r_, unsigned voff, unsigned soff, unsigned lds_dst) {
+    const i32x4 r = {__builtin_amdgcn_readfirstlane(r_.x), __builtin_amdgcn_readfirstlane(r_.y),
+                     __builtin_amdgcn_readfirstlane(r_.z), __builtin_amdgcn_readfirstlane(r_.w)};
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory", "m0");
+  };
+  const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+  const unsigned total = my_panels * (unsigned)NPOS;
+  unsigned ld_t = 0, ld_j = 0;
+  // the position being issued (ld_t; ld_j inside its panel): W1 tile -> W1 stage ld_t & 1, W2 slice of position ld_t - 1 -> W2
+  // stage (ld_t - 1) & 1.  begin() fixes the scalars, w1(i) / w2(i) issue one piece each, end() advances.
+  unsigned is_v1 = OOBA, is_s1 = 0, is_d1 = 0, is_s2 = 0, is_d2 = 0;
+  bool is_live2 = false;
+  auto issue_begin = [&]() {
+    const bool live1 = ld_t < total;
+    const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;
+    is_live2 = ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NSTEP);
+    is_v1 = live1 ? w1_lane : OOBA;
+    is_s1 = __builtin_amdgcn_readfirstlane(ld_j * (unsigned)W1_TILE);
+    is_d1 = __builtin_amdgcn_readfirstlane(smem_base + (ld_t & 1u) * (unsigned)STAGE);
+    is_s2 = __builtin_amdgcn_readfirstlane((j2 - (unsigned)NPRE) * 64u);
+    is_d2 = __builtin_amdgcn_readfirstlane(smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE);
+  };
+  auto issue_w1 = [&](int i) {
+    const unsigned p = pr + 4u * (unsigned)i, kb = p >> 3, rg = p & 7u;
+    dma(rW1, is_v1, is_s1 + rg * (8u * ROWB1) + kb * 128u, is_d1 + p * 1024u);
+  };
+  auto issue_w2 = [&](int i) {   // (caller knows the slice is live)
+    const unsigned d = pr + 4u * (unsigned)i;
+    dma(rW2, w2_lane, is_s2 + d * (16u * HID * 2u), is_d2 + d * 1024u);
+  };
+  auto issue_end = [&]() {
+    ld_t = __builtin_amdgcn_readfirstlane(ld_t + 1u);
+    ld_j = __builtin_amdgcn_readfirstlane(ld_j + 1u == (unsigned)NPOS ? 0u : ld_j + 1u);
+  };
+  auto issue_all = [&]() {   // one burst (positions outside the feed-forward loop)
+    issue_begin();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_w1(i);
+    if (is_live2) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) issue_w2(i);
+    }
+    issue_end();
+  };
+
+  // fragment indices (uint4 units), as ff_fused.hip: W1-region tile row 16 n4 + li, logical chunk 4 ks + lg
+  const unsigned bq0 = (unsigned)li * 8u + (unsigned)(lg ^ (li & 7));
+  const unsigned bq1 = (unsigned)li * 8u + (unsigned)((4 + lg) ^ (li & 7));
+  const unsigned w2q = (unsigned)(W1_TILE / 16) + (unsigned)li * 4u + (unsigned)(lg ^ (2 * ((li >> 3) & 1)));   // W2 row 16 nt + li
+  constexpr unsigned BIAS_Q = BIAS_OFF / 16;
+
+  issue_all();      // W1-region tile 0
+  __syncthreads();  // bias image complete
+
+  unsigned t = 0;
+  for (unsigned panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
+    const int64_t M0 = (int64_t)panel * BM;
+    const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<uint16_t*>(g.A + M0 * g.lda), 0, (int)(((rows_valid - 1) * g.lda + C) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<float*>(g.res + M0 * g.ldr), 0, (int)(((rows_valid - 1) * g.ldr + C) * 4), 0x00020000);
+    // ---- this wave's 32 x 320 slice of the operand in MFMA layout: row 32 pr + 16 mi + li, k = 32 ks + 8 lg .. + 7 ----
+    uint4 fa[2][KS];
+    const unsigned a_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2));
+    const unsigned a_mi = (unsigned)(16 * g.lda * 2);
+    auto load_a = [&]() {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, MIMO_LD_AUX));
+    };
+    if constexpr (!TAIL) load_a();
+    // ---- accumulators: lane (li, lg) owns columns 16 nt + 4 lg .. + 3 of rows 16 mi + li for all 20 column tiles ----
+    f32x4 acc2[20][2];
+    const unsigned r_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 4 * lg) * 4));
+    const unsigned bcol = pinned(BIAS_Q + (unsigned)lg);
+    const unsigned r_mi = (unsigned)(16 * g.ldr * 4);
+#pragma unroll
+    for (int nt = 0; nt < 20; ++nt) {
+      const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((TAIL ? 10 : 8) * C / 4 + 4 * nt)]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, MIMO_LD_AUX)) + bv;
+    }
+    // one 64-row tile of a [C, C] weight (rows in the tile order of pack_proj_tail: n-tiles 0, 1 = output columns 32 q .. + 31,
+    // n-tiles 2, 3 = 160 + 32 q .. + 31) in the W1 region of stage t & 1, times the operand in fa.  ISSUE: this wave's pieces of
+    // the next position go out between the k-steps.
+    auto proj = [&](auto q_c, auto issue_c) {
+      constexpr int q = decltype(q_c)::value;
+      constexpr bool ISSUE = decltype(issue_c)::value != 0;
+      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+      if constexpr (ISSUE) issue_begin();
+      uint4 wf[2][4];
+      auto load4 = [&](auto ks_c, uint4 (&dst)[4]) {
+        constexpr int ks = decltype(ks_c)::value;
+        const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) dst[n4] = smem[qq + (unsigned)n4 * 128u];
+      };
+      load4(ICf<0>{}, wf[0]);
+      // segments of eight MFMAs (one k-step), the next k-step's fragments fetched one segment ahead
+      static_for<0, KS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if constexpr (ks + 1 < KS) load4(ICf<ks + 1>{}, wf[(ks + 1) & 1]);
+        if constexpr (ISSUE) issue_w1(ks);
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi] = HT<DT>::mfma16(wf[ks & 1][n4], fa[mi][ks], acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (ISSUE) {
+        if (is_live2) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) issue_w2(i);
+        }
+        issue_end();
+      }
+    };
+    // the accumulators as the next MFMA operand (k order inside a 32-block = the accumulator layout, the consuming weight is
+    // packed with pack_ff2_kperm): k-step 5 h + kk = column tiles 10 h + 2 kk, 10 h + 2 kk + 1
+    auto acc_to_operand = [&](auto&& f) {   // f(nt, mi) -> f32x4
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int n0 = 10 * (ks / 5) + 2 * (ks % 5);
+          const f32x4 a0 = f(n0, mi), a1 = f(n0 + 1, mi);
+          fa[mi][ks] = make_uint4(pack2<DT>(a0[0], a0[1]), pack2<DT>(a0[2], a0[3]), pack2<DT>(a1[0], a1[1]), pack2<DT>(a1[2], a1[3]));
+        }
+    };
+
+    if constexpr (TAIL) {
+      if (g.img_bias) {
+        // the per-image vector (the collapsed cross-attention of the spatial blocks): rows_per_img >= 128, a panel holds rows of
+        // at most two images
+        const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
+        const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
+        const int64_t img0 = M0 / g.rows_per_img;
+        const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);
+        const unsigned ib_off = (unsigned)((img0 * g.ldib + 4 * lg) * 4);
+        const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const unsigned o = ib_off + ((int)(pr * 32) + 16 * mi + li >= next0 ? step : 0u);
+#pragma unroll
+          for (int nt = 0; nt < 20; ++nt)
+            acc2[nt][mi] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + nt * 64, 0, 0));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a();
+      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<0>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<1>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<2>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<3>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<4>{}, ICf<1>{}); ++t;
+      // LayerNorm over the row's 320 columns, with the arithmetic of ff_fused_kernel (which holds the row in two halves of 160
+      // columns on two waves): per half a local sum and a local centred sum of squares, combined by the pairwise update
+      float mean[2], rstd[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        float hs[2], hq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float sum = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 10; ++nt)
+            sum += (acc2[10 * h + nt][mi][0] + acc2[10 * h + nt][mi][1]) + (acc2[10 * h + nt][mi][2] + acc2[10 * h + nt][mi][3]);
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float ml = sum * (1.f / 160.f);
+          float qq = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = acc2[10 * h + nt][mi][r] - ml;
+              qq = fmaf(d, d, qq);
+            }
+          qq += __shfl_xor(qq, 16, 64);
+          qq += __shfl_xor(qq, 32, 64);
+          hs[h] = sum; hq[h] = qq;
+        }
+        const float dm = (hs[0] - hs[1]) * (1.f / 160.f);
+        mean[mi] = (hs[0] + hs[1]) * (1.f / 320.f);
+        rstd[mi] = rsqrtf(((hq[0] + hq[1]) + 80.f * dm * dm) * (1.f / 320.f) + g.ln_eps);
+      }
+      acc_to_operand([&](int nt, int mi) -> f32x4 {
+        const f32x4 gm = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(11 * C / 4 + 4 * nt)]);
+        const f32x4 bt = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(12 * C / 4 + 4 * nt)]);
+        return (acc2[nt][mi] - mean[mi]) * rstd[mi] * gm + bt;
+      });
+      // the feed-forward accumulates on y + b2
+#pragma unroll
+      for (int nt = 0; nt < 20; ++nt) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(8 * C / 4 + 4 * nt)]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc2[nt][mi] += bv;
+      }
+    }
+
+    // ---- feed-forward, 40 positions.  A position = 30 SEGMENTS of four MFMAs: 0..9 FF1 of the W1 tile's value/gate pair 0
+    // (k-step = segment), 10..19 FF1 of pair 1, 20..29 FF2 of the PREVIOUS chunk (column tiles 2 s, 2 s + 1).  A segment is
+    // fenced (sched_barrier): the two W fragments of segment s + 2 are fetched from LDS, at most one DMA piece of the next
+    // position goes out, the four MFMAs are issued, and one stage of the GEGLU units that are in flight runs in their shadow.
+    // A GEGLU unit = one 16 x 16 value / gate tile pair (4 values per lane), 10 stages of 4-12 VALU instructions. ----
+    f32x4 acc1[4][2];
+    struct GU { float x[4], u[4], v[4], p[4]; u32x2 out; };
+    auto gu_stage = [&](GU& s, auto st_c, const f32x4& val, const f32x4& gate, const f32x4& bval, const f32x4& bgate) {
+      // gelu_erf_f (common.hip.h) spread over stages; scalar VALU on purpose (packed fp32 ops are slow beside MFMAs)
+      constexpr int st = decltype(st_c)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (st == 0) {
+          s.x[r] = gate[r] + bgate[r];
+          s.v[r] = val[r] + bval[r];
+          s.u[r] = __builtin_amdgcn_fmed3f(__builtin_fabsf(s.x[r]), 0.f, 6.0f);
+        } else if constexpr (st == 1) {
+          s.p[r] = fmaf(GELU_P[7], s.u[r], GELU_P[6]);
+        } else if constexpr (st <= 6) {
+          s.p[r] = fmaf(s.p[r], s.u[r], GELU_P[7 - st]);
+        } else if constexpr (st == 7) {
+          s.p[r] = fmaf(s.p[r], s.u[r], GELU_P[0]);
+          s.x[r] = fmaxf(s.x[r], 0.f);
+        } else if constexpr (st == 8) {
+          s.p[r] = __builtin_amdgcn_exp2f(s.p[r]);
+        } else {
+          s.p[r] = s.v[r] * fmaf(-s.u[r], s.p[r], s.x[r]);
+        }
+      }
+      if constexpr (st == 9) {
+        s.out.x = pack2<DT>(s.p[0], s.p[1]);
+        s.out.y = pack2<DT>(s.p[2], s.p[3]);
+      }
+    };
+    auto gu_all = [&](GU& s, const f32x4& val, const f32x4& gate, const f32x4& bval, const f32x4& bgate) {
+      static_for<0, 10>([&](auto st_c) { gu_stage(s, st_c, val, gate, bval, bgate); });
+    };
+    // b1 of chunk j, pair p: value bias | gate bias of hidden columns 32 j + 16 p + 4 lg + r
+    auto bias_val = [&](unsigned j, int p) { return __builtin_bit_cast(f32x4, smem[BIAS_Q + 16u * j + (unsigned)(8 * p) + (unsigned)lg]); };
+    auto bias_gate = [&](unsigned j, int p) { return __builtin_bit_cast(f32x4, smem[BIAS_Q + 16u * j + (unsigned)(8 * p + 4) + (unsigned)lg]); };
+    auto frag_load = [&](auto seg_c, unsigned sq, unsigned wq, uint4 (&dst)[2]) {
+      constexpr int seg = decltype(seg_c)::value;
+      if constexpr (seg < 20) {
+        const int p = seg / 10, ks = seg % 10;
+        const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
+        dst[0] = smem[qq + (unsigned)(2 * p) * 128u];
+        dst[1] = smem[qq + (unsigned)(2 * p + 1) * 128u];
+      } else {
+        const int nt = 2 * (seg - 20);
+        dst[0] = smem[wq + (unsigned)nt * 64u];
+        dst[1] = smem[wq + (unsigned)(nt + 1) * 64u];
+      }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto seg_mma = [&](auto seg_c, const uint4 (&src)[2], const uint4 (&hf)[2]) {
+      constexpr int seg = decltype(seg_c)::value;
+      if constexpr (seg < 20) {
+        const int p = seg / 10, ks = seg % 10;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          acc1[2 * p][mi] = HT<DT>::mfma16(src[0], fa[mi][ks], ks == 0 ? zero4 : acc1[2 * p][mi]);
+          acc1[2 * p + 1][mi] = HT<DT>::mfma16(src[1], fa[mi][ks], ks == 0 ? zero4 : acc1[2 * p + 1][mi]);
+        }
+      } else {
+        const int nt = 2 * (seg - 20);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc2[nt + i][mi] = HT<DT>::mfma16(src[i], hf[mi], acc2[nt + i][mi]);
+      }
+    };
+
+    u32x2 hA[2], hB[2];          // the previous chunk, packed: pair 0 / pair 1, per row tile
+    f32x4 cv, cg, cbv, cbg;      // pair 1, rows 16..31 of the previous chunk and its b1 values: that GEGLU unit runs under the
+                                 // next position's first segments
+    // first position of the feed-forward: no previous chunk (segments 0..19, the GEGLU of pair 0 / rows 0..15 under pair 1)
+    {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+      issue_begin();
+      uint4 fr[3][2];
+      const uint4 hf0[2] = {};
+      frag_load(ICf<0>{}, sq, 0u, fr[0]);
+      frag_load(ICf<1>{}, sq, 0u, fr[1]);
+      GU u2, u3, u4;
+      const f32x4 bv0 = bias_val(0u, 0), bg0 = bias_gate(0u, 0);
+      cbv = bias_val(0u, 1); cbg = bias_gate(0u, 1);
+      static_for<0, 20>([&](auto seg_c) {
+        constexpr int seg = decltype(seg_c)::value;
+        if constexpr (seg + 2 < 20) frag_load(ICf<seg + 2>{}, sq, 0u, fr[(seg + 2) % 3]);
+        if constexpr (seg < 10) issue_w1(seg);
+        else if constexpr ((seg & 1) != 0) issue_w2((seg - 10) >> 1);
+        seg_mma(seg_c, fr[seg % 3], hf0);
+        if constexpr (seg >= 10) gu_stage(u2, ICf<seg - 10>{}, acc1[0][0], acc1[1][0], bv0, bg0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      issue_end();
+      gu_all(u3, acc1[0][1], acc1[1][1], bv0, bg0);
+      gu_all(u4, acc1[2][0], acc1[3][0], cbv, cbg);
+      hA[0] = u2.out; hA[1] = u3.out; hB[0] = u4.out;
+      cv = acc1[2][1]; cg = acc1[3][1];
+      ++t;
+    }
+#pragma unroll 1
+    for (unsigned j = 1; j < (unsigned)NSTEP; ++j, ++t) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+      const unsigned wq = ((t + 1u) & 1u) * (unsigned)(STAGE / 16) + w2q;
+      issue_begin();
+      uint4 fr[3][2];
+      uint4 hf[2] = {};
+      frag_load(ICf<0>{}, sq, wq, fr[0]);
+      frag_load(ICf<1>{}, sq, wq, fr[1]);
+      GU u1, u2, u3, u4;
+      f32x4 bv0 = zero4, bg0 = zero4, bv1 = zero4, bg1 = zero4;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 30>([&](auto seg_c) {
+        constexpr int seg = decltype(seg_c)::value;
+        if constexpr (seg + 2 < 30) frag_load(ICf<seg + 2>{}, sq, wq, fr[(seg + 2) % 3]);
+        if constexpr (seg == 9) { bv0 = bias_val(j, 0); bg0 = bias_gate(j, 0); }
+        if constexpr (seg == 19) { bv1 = bias_val(j, 1); bg1 = bias_gate(j, 1); }
+        if constexpr (seg < 10) issue_w1(seg);
+        else if constexpr (seg < 20 && (seg & 1) != 0) issue_w2((seg - 10) >> 1);
+        if constexpr (seg == 20) {
+          hf[0] = make_uint4(hA[0].x, hA[0].y, hB[0].x, hB[0].y);
+          hf[1] = make_uint4(hA[1].x, hA[1].y, hB[1].x, hB[1].y);
+        }
+        seg_mma(seg_c, fr[seg % 3], hf);
+        if constexpr (seg < 10) {
+          gu_stage(u1, seg_c, cv, cg, cbv, cbg);                       // chunk j - 1, pair 1, rows 16..31
+          if constexpr (seg == 9) hB[1] = u1.out;
+        } else {
+          if constexpr (seg < 20) gu_stage(u2, ICf<seg - 10>{}, acc1[0][0], acc1[1][0], bv0, bg0);   // chunk j, pair 0, rows 0..15
+          if constexpr ((seg & 1) == 0) gu_stage(u3, ICf<(seg - 10) / 2>{}, acc1[0][1], acc1[1][1], bv0, bg0);   // chunk j, pair 0, rows 16..31
+          if constexpr (seg >= 20) gu_stage(u4, ICf<seg - 20>{}, acc1[2][0], acc1[3][0], bv1, bg1);   // chunk j, pair 1, rows 0..15
+        }
+        if constexpr (seg == 19) issue_end();
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      hA[0] = u2.out; hA[1] = u3.out; hB[0] = u4.out;
+      cv = acc1[2][1]; cg = acc1[3][1]; cbv = bv1; cbg = bg1;
+    }
+    // drain: FF2 of the panel's last chunk (its W2 slice was issued in the last step)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (TAIL) issue_all();  // second projection tile (the first one was issued in the last FF step and has landed)
+    {
+      GU u1;
+      gu_all(u1, cv, cg, cbv, cbg);
+      hB[1] = u1.out;
+      const uint4 hf[2] = {make_uint4(hA[0].x, hA[0].y, hB[0].x, hB[0].y), make_uint4(hA[1].x, hA[1].y, hB[1].x, hB[1].y)};
+      const unsigned wq = ((t + 1u) & 1u) * (unsigned)(STAGE / 16) + w2q;
+      uint4 fr[2][2];
+      frag_load(ICf<20>{}, 0u, wq, fr[0]);
+      static_for<20, 30>([&](auto seg_c) {
+        constexpr int seg = decltype(seg_c)::value;
+        if constexpr (seg + 1 < 30) frag_load(ICf<seg + 1>{}, 0u, wq, fr[(seg + 1) & 1]);
+        seg_mma(seg_c, fr[seg & 1], hf);
+      });
+    }
+    const int row0 = (int)pr * 32 + li;
+    if constexpr (!TAIL) {
+      // ---- half output, 16-byte stores through the lane exchange of gemm_conv.hip's paired epilogue ----
+      const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + C) * 2), 0x00020000);
+#pragma unroll
+      for (int nt = 0; nt < 20; ++nt) {
+        const f32x4 va = acc2[nt][0], vb = acc2[nt][1];
+        const auto sx = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[0], va[1]), pack2<DT>(vb[0], vb[1]), false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pack2<DT>(va[2], va[3]), pack2<DT>(vb[2], vb[3]), false, false);
+        const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+        const unsigned row = (unsigned)(row0 + (lg & 1) * 16);
+        const unsigned c8 = 16u * (unsigned)nt + 4u * (unsigned)(lg & ~1);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rO, (row * (unsigned)g.ldo + c8) * 2u, 0, MIMO_ST_AUX);
+      }
+    } else {
+      // ---- the block's output projection: out32 = x + z @ Wp^T + bp, z = the feed-forward result in the accumulators ----
+      const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(g.out32 + M0 * g.ldo32), 0, (int)(((rows_valid - 1) * g.ldo32 + C) * 4), 0x00020000);
+      acc_to_operand([&](int nt, int mi) -> f32x4 { return acc2[nt][mi]; });
+      const unsigned x_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 4 * lg) * 4));
+      const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
+#pragma unroll
+      for (int nt = 0; nt < 20; ++nt) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(9 * C / 4 + 4 * nt)]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, MIMO_LD_AUX)) + bv;
+      }
+      // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, multiply (+ issue the next)
+      proj(ICf<0>{}, ICf<0>{});
+      ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<1>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<2>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<3>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<4>{}, ICf<1>{}); ++t;
+      static_assert(NTAIL == 5, "projection tiles are spelled out");
+      const unsigned o_off = pinned(((unsigned)row0 * (unsigned)g.ldo32 + 4u * (unsigned)lg) * 4u);
+      const unsigned o_mi = 16u * (unsigned)g.ldo32 * 4u;
+#pragma unroll
+      for (int nt = 0; nt < 20; ++nt)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
+                                                 o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, MIMO_ST_AUX);
+      // ---- optional: GroupNorm column statistics of out32 per 32-row slab = this wave's rows (layout and arithmetic of
+      // ff_fused_kernel / mimo_gemm_ext's colstats) ----
+      if (g.colstats) {
+        auto dpp = [](float v, auto ctrl_c) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+        };
+        auto row16_sum = [&](float v) {
+          v += dpp(v, ICf<0xB1>{});   // quad_perm [1,0,3,2]
+          v += dpp(v, ICf<0x4E>{});   // quad_perm [2,3,0,1]
+          v += dpp(v, ICf<0x141>{});  // row_half_mirror
+          v += dpp(v, ICf<0x140>{});  // row_mirror
+          return v;
+        };
+        const __amdgpu_buffer_rsrc_t rCS = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.colstats + (M0 >> 5) * 2 * C), 0, (int)(((rows_valid + 31) >> 5) * 2 * C * 4), 0x00020000);
+        const unsigned cs_off = pinned(li == 0 ? (unsigned)((pr * 2 * C + 4 * lg) * 4) : 0x80000000u);
+#pragma unroll
+        for (int nt = 0; nt < 20; ++nt) {
+          f32x4 s = acc2[nt][0] + acc2[nt][1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r] = row16_sum(s[r]);
+          const f32x4 mean_c = s * (1.0f / 32.0f);
+          const f32x4 d0 = acc2[nt][0] - mean_c, d1 = acc2[nt][1] - mean_c;
+          f32x4 q = d0 * d0 + d1 * d1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean_c), rCS, cs_off + 64u * (unsigned)nt, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rCS, cs_off + 64u * (unsigned)nt, (unsigned)(C * 4), 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
+}
+
+template <int DT>
+void ff4_launch_dt(const FFArgs& g, int mode, unsigned grid, hipStream_t st) {
+  if (mode == 2) hipLaunchKernelGGL((ff4_kernel<DT, 2>), dim3(grid), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((ff4_kernel<DT, 0>), dim3(grid), dim3(256), 0, st, g);
+}
+
+}  // namespace
+
+// called by ff_launch (ff_fused.hip) for MODE 0 / 2
+void mimo_ff4_launch(int dtype, const void* args, int mode, unsigned grid, void* stream) {
+  const FFArgs& g = *static_cast<const FFArgs*>(args);
+  if (dtype == MIMO_F16) ff4_launch_dt<MIMO_F16>(g, mode, grid, (hipStream_t)stream);
+  else ff4_launch_dt<MIMO_BF16>(g, mode, grid, (hipStream_t)stream);
+}
