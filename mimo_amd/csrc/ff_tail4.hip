@@ -23,9 +23,31 @@
 // ff_fused.hip; the weight tensors are the ones mimo_amd.packing already makes.
 #include "ff_fused.hip.h"
 
+// Compile-time experiment knobs (tools/ff4_variants.py builds one small library per setting; the shipped library uses the defaults)
+#ifndef FF4_ABLATE    // timing experiments of the feed-forward positions (results are wrong): 1 no DMA issue, 2 no GEGLU VALU,
+#define FF4_ABLATE 0  //   4 no MFMAs, 8 no W fragment reads from LDS, 16 no per-position wait + barrier
+#endif
+#ifndef FF4_FENCE     // 1: sched_barrier between segments
+#define FF4_FENCE 1
+#endif
+#ifndef FF4_PF        // W fragments are fetched this many segments ahead (1 | 2)
+#define FF4_PF 2
+#endif
+#ifndef FF4_BIAS_INIT // 1: the FF1 accumulators start from b1 instead of zero (the GEGLU's two bias additions disappear; the sum
+#define FF4_BIAS_INIT 0 //  is then b + sum(a w) instead of sum(a w) + b: not bit-identical to ff_fused_kernel any more)
+#endif
+#ifndef FF4_TOUCH     // 1: during the feed-forward positions the waves touch (4-byte LDS-DMA loads into a junk LDS row, one 128-byte line
+#define FF4_TOUCH 0   //    per lane) the NEXT panel's operand rows and this panel's x rows: every block reaches its panel boundary at the
+#endif                //    same time, and the burst of operand loads there is an HBM-bound stall of the whole chip
+#define FF4_LD_BYTES(x) (x)
+#define FF4_LD_ROW0(m0) (((FF4_ABLATE) & 32) ? (int64_t)0 : (m0))   // 32: every panel loads the operand rows of panel 0 (cache hits, same statistics)
+#define FF4_ST_BYTES(x) (((FF4_ABLATE) & 64) ? 0 : (x))   // 64: no output stores (dropped by the range check)
+#define FF4_SEG_FENCE() do { if (FF4_FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
+
 namespace {
 
-constexpr int LDS4_BYTES = XCH_OFF;   // two weight stages + the bias image (no exchange buffers)
+constexpr int LDS4_JUNK = XCH_OFF;    // 256 bytes nobody reads: the destination of the touch loads
+constexpr int LDS4_BYTES = XCH_OFF + 256;   // two weight stages + the bias image (no exchange buffers)
 
 // compile-time loop: f(ICf<I>{}) for I in [A, B) — every register-array index below is a constant expression
 template <int A, int B, class F>
@@ -118,6 +140,19 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     issue_end();
   };
 
+  // touch(base, row0, ld_bytes, row_bytes, k): lane i of the k-th touch instruction of a [128 x row_bytes] panel starting at row
+  // row0 fetches 4 bytes of line (64 k + i) of the panel (lines counted row by row); rows are clamped to the tensor
+  [[maybe_unused]] auto touch = [&](const void* base, int64_t row0, int64_t ld_bytes, unsigned row_bytes, unsigned k) {
+    const unsigned lpr = row_bytes >> 7;                       // 128-byte lines per row (5 | 10)
+    const unsigned tl = k * 64u + (unsigned)lane;
+    const unsigned row = tl / lpr, line = tl - row * lpr;
+    int64_t r = row0 + (int64_t)row;
+    r = r < g.M ? r : g.M - 1;
+    const char* ptr = static_cast<const char*>(base) + r * ld_bytes + (int64_t)line * 128;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(ptr), "s"(__builtin_amdgcn_readfirstlane(smem_base + (unsigned)LDS4_JUNK)) : "memory", "m0");
+  };
+
   // fragment indices (uint4 units), as ff_fused.hip: W1-region tile row 16 n4 + li, logical chunk 4 ks + lg
   const unsigned bq0 = (unsigned)li * 8u + (unsigned)(lg ^ (li & 7));
   const unsigned bq1 = (unsigned)li * 8u + (unsigned)((4 + lg) ^ (li & 7));
@@ -128,13 +163,15 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
   __syncthreads();  // bias image complete
 
   unsigned t = 0;
+  [[maybe_unused]] unsigned tr = 0;   // tune build: thread 0 of block 0 stamps the cycle counter behind every position's barrier
   for (unsigned panel = blockIdx.x; panel < npanels; panel += gridDim.x) {
     const int64_t M0 = (int64_t)panel * BM;
     const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
+    FF_TRACE(g, tr, 10);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)const_cast<uint16_t*>(g.A + M0 * g.lda), 0, (int)(((rows_valid - 1) * g.lda + C) * 2), 0x00020000);
+        (void*)const_cast<uint16_t*>(g.A + FF4_LD_ROW0(M0) * g.lda), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.lda + C) * 2)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)const_cast<float*>(g.res + M0 * g.ldr), 0, (int)(((rows_valid - 1) * g.ldr + C) * 4), 0x00020000);
+        (void*)const_cast<float*>(g.res + FF4_LD_ROW0(M0) * g.ldr), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.ldr + C) * 4)), 0x00020000);
     // ---- this wave's 32 x 320 slice of the operand in MFMA layout: row 32 pr + 16 mi + li, k = 32 ks + 8 lg .. + 7 ----
     uint4 fa[2][KS];
     const unsigned a_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2));
@@ -230,11 +267,11 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       load_a();
       // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<0>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<1>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<2>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<3>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<4>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 11); proj(ICf<0>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 12); proj(ICf<1>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 13); proj(ICf<2>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 14); proj(ICf<3>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 15); proj(ICf<4>{}, ICf<1>{}); ++t;
       // LayerNorm over the row's 320 columns, with the arithmetic of ff_fused_kernel (which holds the row in two halves of 160
       // columns on two waves): per half a local sum and a local centred sum of squares, combined by the pairwise update
       float mean[2], rstd[2];
@@ -290,11 +327,15 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     auto gu_stage = [&](GU& s, auto st_c, const f32x4& val, const f32x4& gate, const f32x4& bval, const f32x4& bgate) {
       // gelu_erf_f (common.hip.h) spread over stages; scalar VALU on purpose (packed fp32 ops are slow beside MFMAs)
       constexpr int st = decltype(st_c)::value;
+      if constexpr ((FF4_ABLATE & 2) != 0) {
+        if constexpr (st == 9) { s.out.x = __float_as_uint(val[0]); s.out.y = __float_as_uint(gate[0]); }
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if constexpr (st == 0) {
-          s.x[r] = gate[r] + bgate[r];
-          s.v[r] = val[r] + bval[r];
+          s.x[r] = FF4_BIAS_INIT ? gate[r] : gate[r] + bgate[r];
+          s.v[r] = FF4_BIAS_INIT ? val[r] : val[r] + bval[r];
           s.u[r] = __builtin_amdgcn_fmed3f(__builtin_fabsf(s.x[r]), 0.f, 6.0f);
         } else if constexpr (st == 1) {
           s.p[r] = fmaf(GELU_P[7], s.u[r], GELU_P[6]);
@@ -322,7 +363,9 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     auto bias_gate = [&](unsigned j, int p) { return __builtin_bit_cast(f32x4, smem[BIAS_Q + 16u * j + (unsigned)(8 * p + 4) + (unsigned)lg]); };
     auto frag_load = [&](auto seg_c, unsigned sq, unsigned wq, uint4 (&dst)[2]) {
       constexpr int seg = decltype(seg_c)::value;
-      if constexpr (seg < 20) {
+      if constexpr ((FF4_ABLATE & 8) != 0) {
+        dst[0] = make_uint4(sq, wq, 1u, 2u); dst[1] = make_uint4(wq, sq, 3u, 4u);
+      } else if constexpr (seg < 20) {
         const int p = seg / 10, ks = seg % 10;
         const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
         dst[0] = smem[qq + (unsigned)(2 * p) * 128u];
@@ -334,14 +377,19 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       }
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto seg_mma = [&](auto seg_c, const uint4 (&src)[2], const uint4 (&hf)[2]) {
+    auto seg_mma = [&](auto seg_c, const uint4 (&src)[2], const uint4 (&hf)[2], const f32x4& iv, const f32x4& ig) {
       constexpr int seg = decltype(seg_c)::value;
-      if constexpr (seg < 20) {
+      if constexpr ((FF4_ABLATE & 4) != 0) {
+        if constexpr (seg % 10 == 0 && seg < 20) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) { acc1[2 * (seg / 10)][mi] = __builtin_bit_cast(f32x4, src[0]); acc1[2 * (seg / 10) + 1][mi] = __builtin_bit_cast(f32x4, src[1]); }
+        }
+      } else if constexpr (seg < 20) {
         const int p = seg / 10, ks = seg % 10;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          acc1[2 * p][mi] = HT<DT>::mfma16(src[0], fa[mi][ks], ks == 0 ? zero4 : acc1[2 * p][mi]);
-          acc1[2 * p + 1][mi] = HT<DT>::mfma16(src[1], fa[mi][ks], ks == 0 ? zero4 : acc1[2 * p + 1][mi]);
+          acc1[2 * p][mi] = HT<DT>::mfma16(src[0], fa[mi][ks], ks == 0 ? (FF4_BIAS_INIT ? iv : zero4) : acc1[2 * p][mi]);
+          acc1[2 * p + 1][mi] = HT<DT>::mfma16(src[1], fa[mi][ks], ks == 0 ? (FF4_BIAS_INIT ? ig : zero4) : acc1[2 * p + 1][mi]);
         }
       } else {
         const int nt = 2 * (seg - 20);
@@ -357,7 +405,9 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
                                  // next position's first segments
     // first position of the feed-forward: no previous chunk (segments 0..19, the GEGLU of pair 0 / rows 0..15 under pair 1)
     {
+      FF_TRACE(g, tr, 18);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      FF_TRACE(g, tr, 19);
       const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
       issue_begin();
       uint4 fr[3][2];
@@ -372,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
         if constexpr (seg + 2 < 20) frag_load(ICf<seg + 2>{}, sq, 0u, fr[(seg + 2) % 3]);
         if constexpr (seg < 10) issue_w1(seg);
         else if constexpr ((seg & 1) != 0) issue_w2((seg - 10) >> 1);
-        seg_mma(seg_c, fr[seg % 3], hf0);
+        seg_mma(seg_c, fr[seg % 3], hf0, seg < 10 ? bv0 : cbv, seg < 10 ? bg0 : cbg);
         if constexpr (seg >= 10) gu_stage(u2, ICf<seg - 10>{}, acc1[0][0], acc1[1][0], bv0, bg0);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -385,29 +435,46 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     }
 #pragma unroll 1
     for (unsigned j = 1; j < (unsigned)NSTEP; ++j, ++t) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr ((FF4_ABLATE & 16) == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      FF_TRACE(g, tr, 1);
       const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
       const unsigned wq = ((t + 1u) & 1u) * (unsigned)(STAGE / 16) + w2q;
       issue_begin();
       uint4 fr[3][2];
       uint4 hf[2] = {};
       frag_load(ICf<0>{}, sq, wq, fr[0]);
-      frag_load(ICf<1>{}, sq, wq, fr[1]);
+      if constexpr (FF4_PF == 2) frag_load(ICf<1>{}, sq, wq, fr[1]);
       GU u1, u2, u3, u4;
       f32x4 bv0 = zero4, bg0 = zero4, bv1 = zero4, bg1 = zero4;
+      if constexpr (FF4_BIAS_INIT != 0) { bv0 = bias_val(j, 0); bg0 = bias_gate(j, 0); }
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, 30>([&](auto seg_c) {
         constexpr int seg = decltype(seg_c)::value;
-        if constexpr (seg + 2 < 30) frag_load(ICf<seg + 2>{}, sq, wq, fr[(seg + 2) % 3]);
-        if constexpr (seg == 9) { bv0 = bias_val(j, 0); bg0 = bias_gate(j, 0); }
-        if constexpr (seg == 19) { bv1 = bias_val(j, 1); bg1 = bias_gate(j, 1); }
-        if constexpr (seg < 10) issue_w1(seg);
-        else if constexpr (seg < 20 && (seg & 1) != 0) issue_w2((seg - 10) >> 1);
+        if constexpr (seg + FF4_PF < 30) frag_load(ICf<seg + FF4_PF>{}, sq, wq, fr[(seg + FF4_PF) % 3]);
+        if constexpr (FF4_BIAS_INIT != 0) {
+          if constexpr (seg == 5) { bv1 = bias_val(j, 1); bg1 = bias_gate(j, 1); }
+        } else {
+          if constexpr (seg == 9) { bv0 = bias_val(j, 0); bg0 = bias_gate(j, 0); }
+          if constexpr (seg == 19) { bv1 = bias_val(j, 1); bg1 = bias_gate(j, 1); }
+        }
+        if constexpr ((FF4_ABLATE & 1) == 0) {
+          if constexpr (seg < 10) issue_w1(seg);
+          else if constexpr (seg < 20 && (seg & 1) != 0) issue_w2((seg - 10) >> 1);
+        }
+        if constexpr (FF4_TOUCH != 0 && seg == 24) {
+          // wave pr issues touch number 4 (j - 1) + pr: 0..9 the next panel's A rows (640 lines), 10..29 its residual rows
+          // (1280 lines), MODE 2: 30..49 this panel's x rows
+          const unsigned ti = (j - 1u) * 4u + pr;
+          const int64_t Mn = M0 + (int64_t)gridDim.x * BM;
+          if (ti < 10u) { if (Mn < g.M) touch(g.A, Mn, g.lda * 2, (unsigned)(C * 2), ti); }
+          else if (ti < 30u) { if (Mn < g.M) touch(g.res, Mn, g.ldr * 4, (unsigned)(C * 4), ti - 10u); }
+          else if (TAIL && ti < 50u) touch(g.x, M0, g.ldx * 4, (unsigned)(C * 4), ti - 30u);
+        }
         if constexpr (seg == 20) {
           hf[0] = make_uint4(hA[0].x, hA[0].y, hB[0].x, hB[0].y);
           hf[1] = make_uint4(hA[1].x, hA[1].y, hB[1].x, hB[1].y);
         }
-        seg_mma(seg_c, fr[seg % 3], hf);
+        seg_mma(seg_c, fr[seg % 3], hf, seg < 10 ? bv0 : bv1, seg < 10 ? bg0 : bg1);
         if constexpr (seg < 10) {
           gu_stage(u1, seg_c, cv, cg, cbv, cbg);                       // chunk j - 1, pair 1, rows 16..31
           if constexpr (seg == 9) hB[1] = u1.out;
@@ -417,13 +484,14 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
           if constexpr (seg >= 20) gu_stage(u4, ICf<seg - 20>{}, acc1[2][0], acc1[3][0], bv1, bg1);   // chunk j, pair 1, rows 0..15
         }
         if constexpr (seg == 19) issue_end();
-        __builtin_amdgcn_sched_barrier(0);
+        FF4_SEG_FENCE();
       });
       hA[0] = u2.out; hA[1] = u3.out; hB[0] = u4.out;
       cv = acc1[2][1]; cg = acc1[3][1]; cbv = bv1; cbg = bg1;
     }
     // drain: FF2 of the panel's last chunk (its W2 slice was issued in the last step)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FF_TRACE(g, tr, 20);
     if constexpr (TAIL) issue_all();  // second projection tile (the first one was issued in the last FF step and has landed)
     {
       GU u1;
@@ -436,14 +504,14 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       static_for<20, 30>([&](auto seg_c) {
         constexpr int seg = decltype(seg_c)::value;
         if constexpr (seg + 1 < 30) frag_load(ICf<seg + 1>{}, 0u, wq, fr[(seg + 1) & 1]);
-        seg_mma(seg_c, fr[seg & 1], hf);
+        seg_mma(seg_c, fr[seg & 1], hf, zero4, zero4);
       });
     }
     const int row0 = (int)pr * 32 + li;
     if constexpr (!TAIL) {
       // ---- half output, 16-byte stores through the lane exchange of gemm_conv.hip's paired epilogue ----
       const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(g.out + M0 * g.ldo), 0, (int)(((rows_valid - 1) * g.ldo + C) * 2), 0x00020000);
+          (void*)(g.out + M0 * g.ldo), 0, FF4_ST_BYTES((int)(((rows_valid - 1) * g.ldo + C) * 2)), 0x00020000);
 #pragma unroll
       for (int nt = 0; nt < 20; ++nt) {
         const f32x4 va = acc2[nt][0], vb = acc2[nt][1];
@@ -457,9 +525,9 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     } else {
       // ---- the block's output projection: out32 = x + z @ Wp^T + bp, z = the feed-forward result in the accumulators ----
       const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)const_cast<float*>(g.x + M0 * g.ldx), 0, (int)(((rows_valid - 1) * g.ldx + C) * 4), 0x00020000);
+          (void*)const_cast<float*>(g.x + FF4_LD_ROW0(M0) * g.ldx), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.ldx + C) * 4)), 0x00020000);
       const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(g.out32 + M0 * g.ldo32), 0, (int)(((rows_valid - 1) * g.ldo32 + C) * 4), 0x00020000);
+          (void*)(g.out32 + M0 * g.ldo32), 0, FF4_ST_BYTES((int)(((rows_valid - 1) * g.ldo32 + C) * 4)), 0x00020000);
       acc_to_operand([&](int nt, int mi) -> f32x4 { return acc2[nt][mi]; });
       const unsigned x_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 4 * lg) * 4));
       const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
@@ -471,13 +539,15 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
           acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, MIMO_LD_AUX)) + bv;
       }
       // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, multiply (+ issue the next)
+      FF_TRACE(g, tr, 23);
       proj(ICf<0>{}, ICf<0>{});
       ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<1>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<2>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<3>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); proj(ICf<4>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 24); proj(ICf<1>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 25); proj(ICf<2>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 26); proj(ICf<3>{}, ICf<1>{}); ++t;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 27); proj(ICf<4>{}, ICf<1>{}); ++t;
       static_assert(NTAIL == 5, "projection tiles are spelled out");
+      FF_TRACE(g, tr, 28);
       const unsigned o_off = pinned(((unsigned)row0 * (unsigned)g.ldo32 + 4u * (unsigned)lg) * 4u);
       const unsigned o_mi = 16u * (unsigned)g.ldo32 * 4u;
 #pragma unroll
@@ -500,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
           return v;
         };
         const __amdgpu_buffer_rsrc_t rCS = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(g.colstats + (M0 >> 5) * 2 * C), 0, (int)(((rows_valid + 31) >> 5) * 2 * C * 4), 0x00020000);
+            (void*)(g.colstats + (M0 >> 5) * 2 * C), 0, FF4_ST_BYTES((int)(((rows_valid + 31) >> 5) * 2 * C * 4)), 0x00020000);
         const unsigned cs_off = pinned(li == 0 ? (unsigned)((pr * 2 * C + 4 * lg) * 4) : 0x80000000u);
 #pragma unroll
         for (int nt = 0; nt < 20; ++nt) {
@@ -518,7 +588,9 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       }
     }
   }
+  FF_TRACE(g, tr, 30);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing all-zero DMAs must not outlive the block's LDS
+  FF_TRACE(g, tr, 31);
 }
 
 template <int DT>

@@ -112,8 +112,59 @@ def bench(dev):
             print(f"{name:11s} {'ff4_kernel (4 waves x 512 regs)' if k else 'ff_fused_kernel (8 waves x 256)':32s} {v:7.3f} ms  {fl / v / 1e9:6.0f} TFLOP/s")
 
 
+TAGS = {10: "panel start", 11: "to_out tile 0", 12: "to_out tile 1", 13: "to_out tile 2", 14: "to_out tile 3", 15: "to_out tile 4",
+        18: "LayerNorm + operand done", 19: "FF position 0", 1: "FF position", 20: "drain", 23: "proj_out tile 0", 24: "proj_out tile 1",
+        25: "proj_out tile 2", 26: "proj_out tile 3", 27: "proj_out tile 4", 28: "stores", 30: "kernel end (before drain wait)", 31: "kernel end"}
+
+
+def trace(dev):
+    """tune build: thread 0 of block 0 stamps the cycle counter behind every position's barrier (ff4_kernel MODE 2)"""
+    import ctypes
+    import numpy as np
+    from mimo_amd import lib as L
+    dt = torch.float16
+    w = weights(dev, dt)
+    M, HW = 48 * 4096, 4096
+    a = torch.randn(M, C, device=dev).to(dt)
+    t = torch.randn(M, C, device=dev)
+    x = torch.randn(M, C, device=dev)
+    ib = torch.randn(48, C, device=dev)
+    use(1)
+    fn = L.load().mimo_tune_trace
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    fn.restype = ctypes.c_int
+    buf = (ctypes.c_ulonglong * 4096)()
+    os.environ["MIMO_FF_TRACE"] = "1"
+    for _ in range(3):
+        run_tail(w, a, t, x, ib, HW, HW)
+        torch.cuda.synchronize()
+        assert fn(buf, 4096) == 0
+    os.environ["MIMO_FF_TRACE"] = "0"
+    v = np.frombuffer(buf, dtype=np.uint64)[:2000]
+    ev = [(int(e >> np.uint64(56)), int(e & np.uint64((1 << 56) - 1))) for e in v if e]
+    print(f"# ff4_kernel<MODE 2> phase trace of block 0, wave 0 (cycle counter behind each position's barrier), {len(ev)} stamps")
+    panel, ff = -1, []
+    for (tg, c), (tg2, c2) in zip(ev, ev[1:]):
+        if tg == 10:
+            panel += 1
+            print(f"panel {panel}")
+        if tg == 1 or tg == 19:
+            ff.append(c2 - c)
+            if tg2 == 20:
+                arr = np.array(ff)
+                print(f"   feed-forward: {len(ff)} positions, {arr.sum()} cycles; per position min {arr.min()} median {int(np.median(arr))} max {arr.max()}"
+                      f" (first {ff[0]}, last {ff[-1]})")
+                ff = []
+            continue
+        print(f"   {TAGS.get(tg, tg):32s} {c2 - c:8d} cycles")
+    print(f"total {ev[-1][1] - ev[0][1]} cycles")
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
+    if "--trace" in sys.argv:
+        trace(dev)
+        sys.exit(0)
     if "--time-only" not in sys.argv:
         check(dev)
     bench(dev)
