@@ -36,6 +36,13 @@
 #ifndef FF4_BIAS_INIT // 1: the FF1 accumulators start from b1 instead of zero (the GEGLU's two bias additions disappear; the sum
 #define FF4_BIAS_INIT 0 //  is then b + sum(a w) instead of sum(a w) + b: not bit-identical to ff_fused_kernel any more)
 #endif
+#ifndef FF4_TRICKLE   // 1 (MODE 2): the fp32 operands are added BEHIND the projections they used to initialise (y = (o Wo^T + bo) + res,
+#define FF4_TRICKLE 1 //    out = (z Wp^T + bp) + x) and their loads trickle in under the projection tiles, eight per tile, behind that tile's
+#endif                //    DMA pieces (counted vmcnt waits); the next panel's half operand is fetched before this panel's stores go out.
+                      //    0: the operand order of ff_fused_kernel (bit-identical to it; tools/ff4_variants.py `exact`)
+#ifndef FF4_DEPHASE   // > 0: every other group of 8 blocks starts this many thousand cycles late.  All blocks walk their panels in
+#define FF4_DEPHASE 0 //    lockstep, so the chip alternates between phases with no HBM traffic at all (the feed-forward positions)
+#endif                //    and HBM-bound bursts (operand loads / stores at the panel boundary); two groups half a panel apart halve the bursts
 #ifndef FF4_TOUCH     // 1: during the feed-forward positions the waves touch (4-byte LDS-DMA loads into a junk LDS row, one 128-byte line
 #define FF4_TOUCH 0   //    per lane) the NEXT panel's operand rows and this panel's x rows: every block reaches its panel boundary at the
 #endif                //    same time, and the burst of operand loads there is an HBM-bound stall of the whole chip
@@ -94,17 +101,26 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
   // W2 slice); wave w moves W1 pieces w, w + 4, ... (10) and W2 pieces w, w + 4, ... (5) of every position ----
   const unsigned w1_lane = ((unsigned)lane >> 3) * (unsigned)ROWB1 + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 3) & 7u)) << 4);
   const unsigned w2_lane = ((unsigned)lane >> 2) * (unsigned)(HID * 2) + ((((unsigned)lane & 3u) ^ (2u * (((unsigned)lane >> 5) & 1u))) << 4);
-  auto dma = [&](const i32x4& r_, unsigned voff, unsigned soff, unsigned lds_dst) {
+  // One LDS-DMA piece in THREE instructions: m0 = LDS base + constant; soffset = stream base + constant (the SALU instruction
+  // between the m0 write and the DMA is the wait state the hardware asks for); the DMA.  All lane- / wave-dependent parts of the
+  // addresses are loop-invariant (voff, the per-wave bases below); the piece index only contributes compile-time constants.
+  auto dma = [&](const i32x4& r_, unsigned voff, unsigned sbase, auto sconst_c, unsigned dbase, auto dconst_c) {
     const i32x4 r = {__builtin_amdgcn_readfirstlane(r_.x), __builtin_amdgcn_readfirstlane(r_.y),
                      __builtin_amdgcn_readfirstlane(r_.z), __builtin_amdgcn_readfirstlane(r_.w)};
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory", "m0");
+    unsigned soff;
+    asm volatile("s_add_u32 m0, %4, %5\n\ts_add_u32 %0, %3, %6\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+                 : "=&s"(soff)
+                 : "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(sbase)), "s"(__builtin_amdgcn_readfirstlane(dbase)),
+                   "i"(decltype(dconst_c)::value), "i"(decltype(sconst_c)::value)
+                 : "memory", "m0", "scc");
   };
   const unsigned my_panels = blockIdx.x < npanels ? (npanels - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
   const unsigned total = my_panels * (unsigned)NPOS;
   unsigned ld_t = 0, ld_j = 0;
   // the position being issued (ld_t; ld_j inside its panel): W1 tile -> W1 stage ld_t & 1, W2 slice of position ld_t - 1 -> W2
   // stage (ld_t - 1) & 1.  begin() fixes the scalars, w1(i) / w2(i) issue one piece each, end() advances.
+  // Wave w moves W1 pieces p = w + 4 i (K-block i >> 1, row group w + 4 (i & 1)) and W2 pieces d = w + 4 i:
+  //   W1 piece: source offset (w + 4 (i & 1)) * 8 rows + (i >> 1) * 128 B, LDS offset (w + 4 i) KB;  W2 piece: 16 d rows, (w + 4 i) KB
   unsigned is_v1 = OOBA, is_s1 = 0, is_d1 = 0, is_s2 = 0, is_d2 = 0;
   bool is_live2 = false;
   auto issue_begin = [&]() {
@@ -112,18 +128,18 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;
     is_live2 = ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NSTEP);
     is_v1 = live1 ? w1_lane : OOBA;
-    is_s1 = __builtin_amdgcn_readfirstlane(ld_j * (unsigned)W1_TILE);
-    is_d1 = __builtin_amdgcn_readfirstlane(smem_base + (ld_t & 1u) * (unsigned)STAGE);
-    is_s2 = __builtin_amdgcn_readfirstlane((j2 - (unsigned)NPRE) * 64u);
-    is_d2 = __builtin_amdgcn_readfirstlane(smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE);
+    is_s1 = __builtin_amdgcn_readfirstlane(ld_j * (unsigned)W1_TILE + pr * (8u * ROWB1));
+    is_d1 = __builtin_amdgcn_readfirstlane(smem_base + (ld_t & 1u) * (unsigned)STAGE + pr * 1024u);
+    is_s2 = __builtin_amdgcn_readfirstlane((j2 - (unsigned)NPRE) * 64u + pr * (16u * HID * 2u));
+    is_d2 = __builtin_amdgcn_readfirstlane(smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE + pr * 1024u);
   };
-  auto issue_w1 = [&](int i) {
-    const unsigned p = pr + 4u * (unsigned)i, kb = p >> 3, rg = p & 7u;
-    dma(rW1, is_v1, is_s1 + rg * (8u * ROWB1) + kb * 128u, is_d1 + p * 1024u);
+  auto issue_w1 = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    dma(rW1, is_v1, is_s1, ICf<(i & 1) * 4 * 8 * ROWB1 + (i >> 1) * 128>{}, is_d1, ICf<i * 4096>{});
   };
-  auto issue_w2 = [&](int i) {   // (caller knows the slice is live)
-    const unsigned d = pr + 4u * (unsigned)i;
-    dma(rW2, w2_lane, is_s2 + d * (16u * HID * 2u), is_d2 + d * 1024u);
+  auto issue_w2 = [&](auto i_c) {   // (caller knows the slice is live)
+    constexpr int i = decltype(i_c)::value;
+    dma(rW2, w2_lane, is_s2, ICf<i * 4 * 16 * HID * 2>{}, is_d2, ICf<i * 4096>{});
   };
   auto issue_end = [&]() {
     ld_t = __builtin_amdgcn_readfirstlane(ld_t + 1u);
@@ -131,12 +147,8 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
   };
   auto issue_all = [&]() {   // one burst (positions outside the feed-forward loop)
     issue_begin();
-#pragma unroll
-    for (int i = 0; i < 10; ++i) issue_w1(i);
-    if (is_live2) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) issue_w2(i);
-    }
+    static_for<0, 10>([&](auto i_c) { issue_w1(i_c); });
+    if (is_live2) static_for<0, 5>([&](auto i_c) { issue_w2(i_c); });
     issue_end();
   };
 
@@ -160,7 +172,62 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
   constexpr unsigned BIAS_Q = BIAS_OFF / 16;
 
   issue_all();      // W1-region tile 0
+  if constexpr (FF4_DEPHASE > 0) {
+    if ((blockIdx.x >> 3) & 1u) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < (unsigned long long)FF4_DEPHASE * 1000ull) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   __syncthreads();  // bias image complete
+
+  constexpr bool TRICKLE = TAIL && FF4_TRICKLE != 0;
+  // ---- a wave's 32 x 320 slice of the half operand in MFMA layout: row 32 pr + 16 mi + li, k = 32 ks + 8 lg .. + 7 ----
+  uint4 fa[2][KS];
+  const unsigned a_off0 = (unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2);
+  const unsigned a_mi = (unsigned)(16 * g.lda * 2);
+  auto desc_a = [&](int64_t m0) {   // (a panel beyond M: empty descriptor, zeros)
+    const int64_t rv = g.M - m0 < (int64_t)BM ? g.M - m0 : (int64_t)BM;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<uint16_t*>(g.A + (rv > 0 ? FF4_LD_ROW0(m0) : 0) * g.lda), 0, rv > 0 ? FF4_LD_BYTES((int)(((rv - 1) * g.lda + C) * 2)) : 0, 0x00020000);
+  };
+  auto desc_r = [&](int64_t m0) {
+    const int64_t rv = g.M - m0 < (int64_t)BM ? g.M - m0 : (int64_t)BM;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<float*>(g.res + (rv > 0 ? FF4_LD_ROW0(m0) : 0) * g.ldr), 0, rv > 0 ? FF4_LD_BYTES((int)(((rv - 1) * g.ldr + C) * 4)) : 0, 0x00020000);
+  };
+  // five of the operand's twenty 16-byte loads (part k = 0..3)
+  auto load_a_part = [&](uint4 (&dst)[2][KS], const __amdgpu_buffer_rsrc_t& rA, auto k_c) {
+    const unsigned a_off = pinned(a_off0);   // (pinned HERE: the ten `offset + constant` must not become ten hoisted registers)
+    static_for<0, 5>([&](auto i_c) {
+      constexpr int i = 5 * decltype(k_c)::value + decltype(i_c)::value, mi = i / KS, ks = i % KS;
+      dst[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, MIMO_LD_AUX));
+    });
+  };
+  auto load_a = [&](int64_t m0) {
+    const __amdgpu_buffer_rsrc_t rA = desc_a(m0);
+    static_for<0, 4>([&](auto k_c) { load_a_part(fa, rA, k_c); });
+  };
+  // column-tile groups: projection tile q completes column tiles 2 q, 2 q + 1, 10 + 2 q, 11 + 2 q; part k (0..3) of a group = one of
+  // them, both row tiles (two 16-byte loads per lane)
+  auto load_part = [&](f32x4 (&dst)[20][2], const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned off_mi, auto gq_c, auto k_c) {
+    constexpr int nt = (decltype(k_c)::value < 2 ? 0 : 10) + 2 * decltype(gq_c)::value + (decltype(k_c)::value & 1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+      dst[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + nt * 64, mi * off_mi, MIMO_LD_AUX));
+  };
+  // TRICKLE: what a panel needs first — its half operand and column-tile group 0 of the residual — is fetched at the END of the
+  // previous panel (the operand under its last projection tile, into fa_next); opr = the fp32 operand that is added behind a
+  // projection (the residual, later x), at most three column-tile groups of it in flight
+  [[maybe_unused]] uint4 fa_next[2][KS];
+  [[maybe_unused]] f32x4 opr[20][2];
+  [[maybe_unused]] const unsigned r_off0 = (unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 4 * lg) * 4);
+  [[maybe_unused]] const unsigned r_mi0 = (unsigned)(16 * g.ldr * 4);
+  if constexpr (TRICKLE) {
+    load_a((int64_t)blockIdx.x * BM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (once: the counted waits below assume tile 0 and the first operand have landed)
+    const __amdgpu_buffer_rsrc_t rR0 = desc_r((int64_t)blockIdx.x * BM);
+    static_for<0, 4>([&](auto k_c) { load_part(opr, rR0, pinned(r_off0), r_mi0, ICf<0>{}, k_c); });
+  }
 
   unsigned t = 0;
   [[maybe_unused]] unsigned tr = 0;   // tune build: thread 0 of block 0 stamps the cycle counter behind every position's barrier
@@ -168,40 +235,41 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     const int64_t M0 = (int64_t)panel * BM;
     const int64_t rows_valid = (g.M - M0) < (int64_t)BM ? (g.M - M0) : (int64_t)BM;
     FF_TRACE(g, tr, 10);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)const_cast<uint16_t*>(g.A + FF4_LD_ROW0(M0) * g.lda), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.lda + C) * 2)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(
         (void*)const_cast<float*>(g.res + FF4_LD_ROW0(M0) * g.ldr), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.ldr + C) * 4)), 0x00020000);
-    // ---- this wave's 32 x 320 slice of the operand in MFMA layout: row 32 pr + 16 mi + li, k = 32 ks + 8 lg .. + 7 ----
-    uint4 fa[2][KS];
-    const unsigned a_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.lda + lg * 8) * 2));
-    const unsigned a_mi = (unsigned)(16 * g.lda * 2);
-    auto load_a = [&]() {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          fa[mi][ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_off + ks * 64, mi * a_mi, MIMO_LD_AUX));
-    };
-    if constexpr (!TAIL) load_a();
+    if constexpr (!TAIL) load_a(M0);
     // ---- accumulators: lane (li, lg) owns columns 16 nt + 4 lg .. + 3 of rows 16 mi + li for all 20 column tiles ----
     f32x4 acc2[20][2];
     const unsigned r_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldr + 4 * lg) * 4));
     const unsigned bcol = pinned(BIAS_Q + (unsigned)lg);
     const unsigned r_mi = (unsigned)(16 * g.ldr * 4);
+    if constexpr (TRICKLE) {
+      // (residual group 0 is on its way; the accumulators start from bo inside the projection tiles)
+    } else {
 #pragma unroll
-    for (int nt = 0; nt < 20; ++nt) {
-      const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((TAIL ? 10 : 8) * C / 4 + 4 * nt)]);
+      for (int nt = 0; nt < 20; ++nt) {
+        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)((TAIL ? 10 : 8) * C / 4 + 4 * nt)]);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, MIMO_LD_AUX)) + bv;
+        for (int mi = 0; mi < 2; ++mi)
+          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, r_off + nt * 64, mi * r_mi, MIMO_LD_AUX)) + bv;
+      }
     }
     // one 64-row tile of a [C, C] weight (rows in the tile order of pack_proj_tail: n-tiles 0, 1 = output columns 32 q .. + 31,
     // n-tiles 2, 3 = 160 + 32 q .. + 31) in the W1 region of stage t & 1, times the operand in fa.  ISSUE: this wave's pieces of
     // the next position go out between the k-steps.
-    auto proj = [&](auto q_c, auto issue_c) {
+    auto no_hook = [](auto) {};
+    auto no_tail = []() {};
+    auto proj = [&](auto q_c, auto issue_c, auto&& hook, auto&& tail_hook, auto init_c) {
       constexpr int q = decltype(q_c)::value;
       constexpr bool ISSUE = decltype(issue_c)::value != 0;
+      constexpr int INIT = decltype(init_c)::value;   // > 0: the tile's accumulators START from row INIT of the bias image (they
+                                                      // come alive here: nothing else has touched this tile's columns yet)
+      f32x4 binit[4];
+      if constexpr (INIT > 0) {
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4)
+          binit[n4] = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(INIT * C / 4 + 4 * (10 * (n4 >> 1) + 2 * q + (n4 & 1)))]);
+      }
       const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
       if constexpr (ISSUE) issue_begin();
       uint4 wf[2][4];
@@ -212,22 +280,25 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
         for (int n4 = 0; n4 < 4; ++n4) dst[n4] = smem[qq + (unsigned)n4 * 128u];
       };
       load4(ICf<0>{}, wf[0]);
-      // segments of eight MFMAs (one k-step), the next k-step's fragments fetched one segment ahead
+      // segments of eight MFMAs (one k-step), the next k-step's fragments fetched one segment ahead; the DMA pieces of the next
+      // position in the first five segments (two each), then the hook's loads (k-steps 5..8: counted waits rely on this order)
       static_for<0, KS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if constexpr (ks + 1 < KS) load4(ICf<ks + 1>{}, wf[(ks + 1) & 1]);
-        if constexpr (ISSUE) issue_w1(ks);
+        if constexpr (ISSUE && ks < 5) { issue_w1(ICf<2 * ks>{}); issue_w1(ICf<2 * ks + 1>{}); }
+        if constexpr (ks >= 5 && ks < 9) hook(ICf<ks - 5>{});
+        if constexpr (ks == 9) tail_hook();   // (behind the hook's loads: the counted waits rely on the order)
 #pragma unroll
         for (int n4 = 0; n4 < 4; ++n4)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
-            acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi] = HT<DT>::mfma16(wf[ks & 1][n4], fa[mi][ks], acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi]);
+            acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi] =
+                HT<DT>::mfma16(wf[ks & 1][n4], fa[mi][ks], (INIT > 0 && ks == 0) ? binit[n4] : acc2[10 * (n4 >> 1) + 2 * q + (n4 & 1)][mi]);
         __builtin_amdgcn_sched_barrier(0);
       });
       if constexpr (ISSUE) {
-        if (is_live2) {
-#pragma unroll
-          for (int i = 0; i < 5; ++i) issue_w2(i);
+        if constexpr (!TAIL) {   // (MODE 2 never has a live W2 slice behind a projection position)
+          if (is_live2) static_for<0, 5>([&](auto i_c) { issue_w2(i_c); });
         }
         issue_end();
       }
@@ -246,32 +317,83 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     };
 
     if constexpr (TAIL) {
-      if (g.img_bias) {
-        // the per-image vector (the collapsed cross-attention of the spatial blocks): rows_per_img >= 128, a panel holds rows of
-        // at most two images
-        const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
-        const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
-        const int64_t img0 = M0 / g.rows_per_img;
-        const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);
-        const unsigned ib_off = (unsigned)((img0 * g.ldib + 4 * lg) * 4);
-        const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
+      // the per-image vector (the collapsed cross-attention of the spatial blocks): rows_per_img >= 128, a panel holds rows of at
+      // most two images
+      auto add_img_bias = [&]() {
+        if (g.img_bias) {
+          const int64_t nimg = (g.M + g.rows_per_img - 1) / g.rows_per_img;
+          const __amdgpu_buffer_rsrc_t rIB = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)const_cast<float*>(g.img_bias), 0, (int)(((nimg - 1) * g.ldib + C) * 4), 0x00020000);
+          const int64_t img0 = M0 / g.rows_per_img;
+          const int next0 = (int)((img0 + 1) * g.rows_per_img - M0);
+          const unsigned ib_off = (unsigned)((img0 * g.ldib + 4 * lg) * 4);
+          const unsigned step = (unsigned)(g.ldib * 4);   // (rows past M read a vector past the table: zeros)
+          // ten loads in flight, then their additions (written as one loop the loads are issued and waited for one by one)
+          auto batch = [&](auto mi_c, auto half_c, unsigned o, bool both) {
+            constexpr int mi = decltype(mi_c)::value, n0 = 10 * decltype(half_c)::value;
+            f32x4 v[10];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const unsigned o = ib_off + ((int)(pr * 32) + 16 * mi + li >= next0 ? step : 0u);
+            for (int i = 0; i < 10; ++i) v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + (n0 + i) * 64, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int nt = 0; nt < 20; ++nt)
-            acc2[nt][mi] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIB, o + nt * 64, 0, 0));
+            for (int i = 0; i < 10; ++i) {
+              acc2[n0 + i][mi] += v[i];
+              if (both) acc2[n0 + i][1] += v[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          };
+          if (next0 >= BM) {   // the whole panel lies in one image (the pipeline's case): both row tiles take the same vector
+            batch(ICf<0>{}, ICf<0>{}, ib_off, true);
+            batch(ICf<0>{}, ICf<1>{}, ib_off, true);
+          } else {
+            const unsigned o0 = ib_off + ((int)(pr * 32) + li >= next0 ? step : 0u);
+            const unsigned o1 = ib_off + ((int)(pr * 32) + 16 + li >= next0 ? step : 0u);
+            batch(ICf<0>{}, ICf<0>{}, o0, false);
+            batch(ICf<0>{}, ICf<1>{}, o0, false);
+            batch(ICf<1>{}, ICf<0>{}, o1, false);
+            batch(ICf<1>{}, ICf<1>{}, o1, false);
+          }
         }
+      };
+      if constexpr (!TRICKLE) {
+        add_img_bias();
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(M0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      load_a();
-      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 11); proj(ICf<0>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 12); proj(ICf<1>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 13); proj(ICf<2>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 14); proj(ICf<3>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 15); proj(ICf<4>{}, ICf<1>{}); ++t;
+      // y = residual + o @ Wo^T + bo: five tiles of Wo (positions 0..4 of the panel).  TRICKLE: the residual's column-tile groups
+      // 1..4 are fetched under tiles 0..3 (group 0 went out at the panel start); group q is added once tile q is through: at most
+      // three groups (96 registers) are in flight.
+      // Counted waits: vmcnt is ONE in-order counter.  Behind the DMA pieces of the tile about to be read this wave has issued,
+      // at tile 0: the operand's 20 loads, the 32 stores of the previous panel's groups 3 and 4, 8 residual loads (the operand
+      // itself was waited for at the end of the previous panel: 40 leaves it and the pieces complete); at tiles 1..4: the 8
+      // loads of the hook.
+      auto add_res = [&](auto gq_c) {
+        static_for<0, 4>([&](auto k_c) {
+          constexpr int nt = (decltype(k_c)::value < 2 ? 0 : 10) + 2 * decltype(gq_c)::value + (decltype(k_c)::value & 1);
+          acc2[nt][0] += opr[nt][0];
+          acc2[nt][1] += opr[nt][1];
+        });
+      };
+      if constexpr (TRICKLE) {
+        asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 11);
+        proj(ICf<0>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rR, r_off, r_mi, ICf<1>{}, k_c); }, no_tail, ICf<10>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 12);
+        proj(ICf<1>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rR, r_off, r_mi, ICf<2>{}, k_c); }, [&]() { add_res(ICf<0>{}); }, ICf<10>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 13);
+        proj(ICf<2>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rR, r_off, r_mi, ICf<3>{}, k_c); }, [&]() { add_res(ICf<1>{}); }, ICf<10>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 14);
+        proj(ICf<3>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rR, r_off, r_mi, ICf<4>{}, k_c); }, [&]() { add_res(ICf<2>{}); }, ICf<10>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 15);
+        proj(ICf<4>{}, ICf<1>{}, no_hook, [&]() { add_res(ICf<3>{}); }, ICf<10>{}); ++t;
+        add_res(ICf<4>{});
+        add_img_bias();
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 11); proj(ICf<0>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 12); proj(ICf<1>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 13); proj(ICf<2>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 14); proj(ICf<3>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 15); proj(ICf<4>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+      }
       // LayerNorm over the row's 320 columns, with the arithmetic of ff_fused_kernel (which holds the row in two halves of 160
       // columns on two waves): per half a local sum and a local centred sum of squares, combined by the pairwise update
       float mean[2], rstd[2];
@@ -420,8 +542,8 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       static_for<0, 20>([&](auto seg_c) {
         constexpr int seg = decltype(seg_c)::value;
         if constexpr (seg + 2 < 20) frag_load(ICf<seg + 2>{}, sq, 0u, fr[(seg + 2) % 3]);
-        if constexpr (seg < 10) issue_w1(seg);
-        else if constexpr ((seg & 1) != 0) issue_w2((seg - 10) >> 1);
+        if constexpr (seg < 10) issue_w1(seg_c);
+        else if constexpr ((seg & 1) != 0) issue_w2(ICf<(seg - 10) / 2>{});
         seg_mma(seg_c, fr[seg % 3], hf0, seg < 10 ? bv0 : cbv, seg < 10 ? bg0 : cbg);
         if constexpr (seg >= 10) gu_stage(u2, ICf<seg - 10>{}, acc1[0][0], acc1[1][0], bv0, bg0);
         __builtin_amdgcn_sched_barrier(0);
@@ -458,8 +580,8 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
           if constexpr (seg == 19) { bv1 = bias_val(j, 1); bg1 = bias_gate(j, 1); }
         }
         if constexpr ((FF4_ABLATE & 1) == 0) {
-          if constexpr (seg < 10) issue_w1(seg);
-          else if constexpr (seg < 20 && (seg & 1) != 0) issue_w2((seg - 10) >> 1);
+          if constexpr (seg < 10) issue_w1(seg_c);
+          else if constexpr (seg < 20 && (seg & 1) != 0) issue_w2(ICf<(seg - 10) / 2>{});
         }
         if constexpr (FF4_TOUCH != 0 && seg == 24) {
           // wave pr issues touch number 4 (j - 1) + pr: 0..9 the next panel's A rows (640 lines), 10..29 its residual rows
@@ -493,6 +615,13 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     FF_TRACE(g, tr, 20);
     if constexpr (TAIL) issue_all();  // second projection tile (the first one was issued in the last FF step and has landed)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)const_cast<float*>(TAIL ? g.x + FF4_LD_ROW0(M0) * g.ldx : nullptr), 0, TAIL ? FF4_LD_BYTES((int)(((rows_valid - 1) * g.ldx + C) * 4)) : 0, 0x00020000);
+    [[maybe_unused]] const unsigned x_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 4 * lg) * 4));
+    [[maybe_unused]] const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
+    if constexpr (TRICKLE) {   // x, column-tile group 0 (behind the DMA pieces just issued; groups 1..4 under the projection tiles)
+      static_for<0, 4>([&](auto k_c) { load_part(opr, rX, x_off, x_mi, ICf<0>{}, k_c); });
+    }
     {
       GU u1;
       gu_all(u1, cv, cg, cbv, cbg);
@@ -524,67 +653,109 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
       }
     } else {
       // ---- the block's output projection: out32 = x + z @ Wp^T + bp, z = the feed-forward result in the accumulators ----
-      const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)const_cast<float*>(g.x + FF4_LD_ROW0(M0) * g.ldx), 0, FF4_LD_BYTES((int)(((rows_valid - 1) * g.ldx + C) * 4)), 0x00020000);
       const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(g.out32 + M0 * g.ldo32), 0, FF4_ST_BYTES((int)(((rows_valid - 1) * g.ldo32 + C) * 4)), 0x00020000);
       acc_to_operand([&](int nt, int mi) -> f32x4 { return acc2[nt][mi]; });
-      const unsigned x_off = pinned((unsigned)(((int64_t)(pr * 32 + li) * g.ldx + 4 * lg) * 4));
-      const unsigned x_mi = (unsigned)(16 * g.ldx * 4);
+      __builtin_amdgcn_sched_barrier(0);   // (the new accumulators must not be created while the old ones are still being packed)
+      if constexpr (!TRICKLE) {   // (TRICKLE: the accumulators start from bp inside the projection tiles)
 #pragma unroll
-      for (int nt = 0; nt < 20; ++nt) {
-        const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(9 * C / 4 + 4 * nt)]);
+        for (int nt = 0; nt < 20; ++nt) {
+          const f32x4 bv = __builtin_bit_cast(f32x4, smem[bcol + (unsigned)(9 * C / 4 + 4 * nt)]);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, MIMO_LD_AUX)) + bv;
+          for (int mi = 0; mi < 2; ++mi)
+            acc2[nt][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, x_off + nt * 64, mi * x_mi, MIMO_LD_AUX)) + bv;
+        }
       }
       // position t (tile 0) landed with the drain's wait; every further tile: wait, barrier, multiply (+ issue the next)
       FF_TRACE(g, tr, 23);
-      proj(ICf<0>{}, ICf<0>{});
-      ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 24); proj(ICf<1>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 25); proj(ICf<2>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 26); proj(ICf<3>{}, ICf<1>{}); ++t;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 27); proj(ICf<4>{}, ICf<1>{}); ++t;
-      static_assert(NTAIL == 5, "projection tiles are spelled out");
-      FF_TRACE(g, tr, 28);
       const unsigned o_off = pinned(((unsigned)row0 * (unsigned)g.ldo32 + 4u * (unsigned)lg) * 4u);
       const unsigned o_mi = 16u * (unsigned)g.ldo32 * 4u;
+      const __amdgpu_buffer_rsrc_t rCS = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(g.colstats ? g.colstats + (M0 >> 5) * 2 * C : nullptr), 0, g.colstats ? FF4_ST_BYTES((int)(((rows_valid + 31) >> 5) * 2 * C * 4)) : 0, 0x00020000);
+      const unsigned cs_off = pinned(li == 0 ? (unsigned)((pr * 2 * C + 4 * lg) * 4) : 0x80000000u);
+      auto dpp = [](float v, auto ctrl_c) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
+      };
+      auto row16_sum = [&](float v) {
+        v += dpp(v, ICf<0xB1>{});   // quad_perm [1,0,3,2]
+        v += dpp(v, ICf<0x4E>{});   // quad_perm [2,3,0,1]
+        v += dpp(v, ICf<0x141>{});  // row_half_mirror
+        v += dpp(v, ICf<0x140>{});  // row_mirror
+        return v;
+      };
+      // one finished column tile leaves: the output rows (two 16-byte stores per lane) and, optionally, the GroupNorm column
+      // statistics of the 32-row slab = this wave's rows (layout and arithmetic of ff_fused_kernel / mimo_gemm_ext's colstats:
+      // mean, then the sum of squared deviations from it; fixed order)
+      auto store_tile = [&](auto nt_c, const f32x4& v0, const f32x4& v1) {
+        constexpr int nt = decltype(nt_c)::value;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rO32, o_off + 64u * (unsigned)nt, 0, MIMO_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rO32, o_off + 64u * (unsigned)nt, o_mi, MIMO_ST_AUX);
+        {   // (without a statistics buffer the descriptor is empty: the stores are dropped, no branch in the tile loop)
+          f32x4 sm = v0 + v1;
 #pragma unroll
-      for (int nt = 0; nt < 20; ++nt)
+          for (int r = 0; r < 4; ++r) sm[r] = row16_sum(sm[r]);
+          const f32x4 mean_c = sm * (1.0f / 32.0f);
+          const f32x4 d0 = v0 - mean_c, d1 = v1 - mean_c;
+          f32x4 qv = d0 * d0 + d1 * d1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qv[r] = row16_sum(qv[r]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean_c), rCS, cs_off + 64u * (unsigned)nt, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), rCS, cs_off + 64u * (unsigned)nt, (unsigned)(C * 4), 0);
+        }
+      };
+      if constexpr (TRICKLE) {
+        // a finished column-tile group: + x, out (8 stores, 16 with the statistics)
+        auto finish = [&](auto gq_c) {
+          static_for<0, 4>([&](auto k_c) {
+            constexpr int nt = (decltype(k_c)::value < 2 ? 0 : 10) + 2 * decltype(gq_c)::value + (decltype(k_c)::value & 1);
+            store_tile(ICf<nt>{}, acc2[nt][0] + opr[nt][0], acc2[nt][1] + opr[nt][1]);
+          });
+        };
+        // x group q is fetched under tile q - 1 (group 0 at the drain) and used when tile q + 1 is nearly through: at most three
+        // groups in flight.  Counted waits, behind the pieces of the tile about to be read: tile 1 — x groups 0, 1: 16 loads;
+        // tiles 2, 3, 4 — 8 loads + the 16 stores of a finished group.
+        proj(ICf<0>{}, ICf<0>{}, [&](auto k_c) { load_part(opr, rX, x_off, x_mi, ICf<1>{}, k_c); }, no_tail, ICf<9>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 24);
+        proj(ICf<1>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rX, x_off, x_mi, ICf<2>{}, k_c); }, [&]() { finish(ICf<0>{}); }, ICf<9>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 25);
+        proj(ICf<2>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rX, x_off, x_mi, ICf<3>{}, k_c); }, [&]() { finish(ICf<1>{}); }, ICf<9>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 26);
+        proj(ICf<3>{}, ICf<1>{}, [&](auto k_c) { load_part(opr, rX, x_off, x_mi, ICf<4>{}, k_c); }, [&]() { finish(ICf<2>{}); }, ICf<9>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 27);
+        // under the last tile: the NEXT panel's half operand (20 loads, behind the pieces of its tile 0, in front of this panel's
+        // last 32 stores: nothing at the next panel's start has to wait for a store)
+        const int64_t M0n = M0 + (int64_t)gridDim.x * BM;
+        const __amdgpu_buffer_rsrc_t rAn = desc_a(M0n);
+        proj(ICf<4>{}, ICf<1>{}, [&](auto k_c) { load_a_part(fa_next, rAn, k_c); }, [&]() { finish(ICf<3>{}); }, ICf<9>{}); ++t;
+        FF_TRACE(g, tr, 28);
+        finish(ICf<4>{});
+        {   // the next panel's residual, column-tile group 0
+          const __amdgpu_buffer_rsrc_t rRn = desc_r(M0n);
+          static_for<0, 4>([&](auto k_c) { load_part(opr, rRn, pinned(r_off0), r_mi0, ICf<0>{}, k_c); });
+        }
+        // an empty asm that READS the next operand: the compiler places its own counted wait for the 20 loads in front of it (it
+        // knows the 40 operations it issued behind them) and from here on treats them as landed
+        asm volatile("" :: "v"(__builtin_bit_cast(u32x4, fa_next[0][0])), "v"(__builtin_bit_cast(u32x4, fa_next[0][1])), "v"(__builtin_bit_cast(u32x4, fa_next[0][2])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[0][3])), "v"(__builtin_bit_cast(u32x4, fa_next[0][4])), "v"(__builtin_bit_cast(u32x4, fa_next[0][5])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[0][6])), "v"(__builtin_bit_cast(u32x4, fa_next[0][7])), "v"(__builtin_bit_cast(u32x4, fa_next[0][8])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[0][9])), "v"(__builtin_bit_cast(u32x4, fa_next[1][0])), "v"(__builtin_bit_cast(u32x4, fa_next[1][1])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[1][2])), "v"(__builtin_bit_cast(u32x4, fa_next[1][3])), "v"(__builtin_bit_cast(u32x4, fa_next[1][4])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[1][5])), "v"(__builtin_bit_cast(u32x4, fa_next[1][6])), "v"(__builtin_bit_cast(u32x4, fa_next[1][7])),
+                     "v"(__builtin_bit_cast(u32x4, fa_next[1][8])), "v"(__builtin_bit_cast(u32x4, fa_next[1][9])) : "memory");
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[nt][mi]), rO32,
-                                                 o_off + 64u * (unsigned)nt, (unsigned)mi * o_mi, MIMO_ST_AUX);
-      // ---- optional: GroupNorm column statistics of out32 per 32-row slab = this wave's rows (layout and arithmetic of
-      // ff_fused_kernel / mimo_gemm_ext's colstats) ----
-      if (g.colstats) {
-        auto dpp = [](float v, auto ctrl_c) {
-          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_c)::value, 0xf, 0xf, true));
-        };
-        auto row16_sum = [&](float v) {
-          v += dpp(v, ICf<0xB1>{});   // quad_perm [1,0,3,2]
-          v += dpp(v, ICf<0x4E>{});   // quad_perm [2,3,0,1]
-          v += dpp(v, ICf<0x141>{});  // row_half_mirror
-          v += dpp(v, ICf<0x140>{});  // row_mirror
-          return v;
-        };
-        const __amdgpu_buffer_rsrc_t rCS = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(g.colstats + (M0 >> 5) * 2 * C), 0, FF4_ST_BYTES((int)(((rows_valid + 31) >> 5) * 2 * C * 4)), 0x00020000);
-        const unsigned cs_off = pinned(li == 0 ? (unsigned)((pr * 2 * C + 4 * lg) * 4) : 0x80000000u);
 #pragma unroll
-        for (int nt = 0; nt < 20; ++nt) {
-          f32x4 s = acc2[nt][0] + acc2[nt][1];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[r] = row16_sum(s[r]);
-          const f32x4 mean_c = s * (1.0f / 32.0f);
-          const f32x4 d0 = acc2[nt][0] - mean_c, d1 = acc2[nt][1] - mean_c;
-          f32x4 q = d0 * d0 + d1 * d1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) q[r] = row16_sum(q[r]);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mean_c), rCS, cs_off + 64u * (unsigned)nt, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rCS, cs_off + 64u * (unsigned)nt, (unsigned)(C * 4), 0);
-        }
+          for (int ks = 0; ks < KS; ++ks) fa[mi][ks] = fa_next[mi][ks];
+      } else {
+        proj(ICf<0>{}, ICf<0>{}, no_hook, no_tail, ICf<0>{});
+        ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 24); proj(ICf<1>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 25); proj(ICf<2>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 26); proj(ICf<3>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); FF_TRACE(g, tr, 27); proj(ICf<4>{}, ICf<1>{}, no_hook, no_tail, ICf<0>{}); ++t;
+        static_assert(NTAIL == 5, "projection tiles are spelled out");
+        FF_TRACE(g, tr, 28);
+        static_for<0, 20>([&](auto nt_c) { store_tile(nt_c, acc2[decltype(nt_c)::value][0], acc2[decltype(nt_c)::value][1]); });
       }
     }
   }

@@ -67,14 +67,21 @@ def check(dev):
             torch.cuda.synchronize()
             e_ff = torch.equal(outs[0][0], outs[1][0])
             e_tl = torch.equal(outs[0][1], outs[1][1])
-            e_cs = True if not cs else torch.equal(outs[0][2], outs[1][2])
             fin = bool(torch.isfinite(outs[1][1]).all())
             d_ff = float((outs[0][0].float() - outs[1][0].float()).abs().max())
-            d_tl = float((outs[0][1] - outs[1][1]).abs().max())
-            ok &= e_ff and e_tl and e_cs and fin
+            r_tl = float((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm())
+            r_cs = 0.0
+            if cs:   # (mean, sum of squared deviations) per 32-row slab and column
+                r_cs = max(float((outs[0][2][:, k] - outs[1][2][:, k]).norm() / outs[0][2][:, k].norm()) for k in (0, 1))
+            # the shipped ff4_kernel adds the fp32 operands BEHIND the projections (FF4_TRICKLE): y and out differ from ff_fused_kernel's by
+            # fp32 rounding order, which flips the half rounding of a few LayerNorm outputs / hidden activations (the same class of
+            # difference the unit tests allow against the torch reference); tools/ff4_variants.py checks the exact-order build of
+            # the same source (-DFF4_TRICKLE=0) against ff_fused_kernel bit for bit
+            good = e_ff and fin and (e_tl or r_tl < (2e-4 if dt == torch.float16 else 4e-4)) and r_cs < 2e-4
+            ok &= good
             print(f"{str(dt)[6:]:9s} M {M:7d} rows/img {rpi:5d}  ff_fused bit-equal {e_ff} (max |d| {d_ff:.2e})  block_tail bit-equal {e_tl} "
-                  f"(max |d| {d_tl:.2e})  colstats {e_cs if cs else '-'}  finite {fin}", flush=True)
-    print("ALL BIT-IDENTICAL" if ok else "MISMATCH")
+                  f"(rel-L2 {r_tl:.2e})  colstats rel-L2 {r_cs:.1e}  finite {fin}  {'ok' if good else 'BAD'}", flush=True)
+    print("ALL GOOD" if ok else "MISMATCH")
     return ok
 
 

@@ -28,6 +28,11 @@ VARIANTS = [
     ("abl_no_loads", ["-DFF4_ABLATE=32"]),
     ("abl_no_stores", ["-DFF4_ABLATE=64"]),
     ("abl_no_io", ["-DFF4_ABLATE=96"]),
+    ("exact", ["-DFF4_TRICKLE=0"]),
+    ("dephase60", ["-DFF4_DEPHASE=60"]),
+    ("dephase100", ["-DFF4_DEPHASE=100"]),
+    ("dephase140", ["-DFF4_DEPHASE=140"]),
+    ("dephase180", ["-DFF4_DEPHASE=180"]),
     ("touch", ["-DFF4_TOUCH=1"]),
     ("bias_init", ["-DFF4_BIAS_INIT=1"]),
     ("touch+bias_init", ["-DFF4_TOUCH=1", "-DFF4_BIAS_INIT=1"]),
@@ -134,10 +139,13 @@ def main():
         for n in names:
             for tag, fn in (("ff", ff), ("tail", tail)):
                 best[(n, tag)] = min(best.get((n, tag), 1e9), timed(fn, libs[n]))
-    ref = {}
+    ref, ref8 = {}, {}
     if "base" in libs:
         ff(libs["base"], pool[0]); ref["ff"] = out_h.clone()
         tail(libs["base"], pool[0]); ref["tail"] = out_f.clone()
+    if "old8" in libs:
+        ff(libs["old8"], pool[0]); ref8["ff"] = out_h.clone()
+        tail(libs["old8"], pool[0]); ref8["tail"] = out_f.clone()
     print(f"# M = {M}, C = {C}, fp16; ms per launch (best of 3 interleaved rounds, cold inputs): mimo_ff_fused | mimo_block_tail_fused")
     for n in names:
         eq = ""
@@ -146,6 +154,8 @@ def main():
             out_f.zero_(); tail(libs[n], pool[0]); e2 = torch.equal(out_f, ref["tail"])
             d = float((out_f - ref["tail"]).norm() / ref["tail"].norm())
             eq = f"   bit-equal to base: {e1 and e2}" + ("" if e1 and e2 else f"  (tail rel-L2 vs base {d:.2e})")
+            if ref8:
+                eq += f"   bit-equal to old8 (ff_fused_kernel): {torch.equal(out_h, ref8['ff']) and torch.equal(out_f, ref8['tail'])}"
         print(f"{n:18s} {best[(n, 'ff')]:7.3f}  {best[(n, 'tail')]:7.3f}{eq}", flush=True)
 
 
