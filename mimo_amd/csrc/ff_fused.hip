@@ -689,7 +689,7 @@ static void ff_launch_dt(const FFArgs& g, int mode, unsigned grid, hipStream_t s
 extern "C" unsigned long long* mimo_tune_trace_buf();
 #endif
 
-// ff_tail4.hip: MODE 0 / 2 on four waves with 512 registers each (bit-identical results)
+// ff_tail4.hip: the block tail (MODE 2) on four waves with 512 registers each
 void mimo_ff4_launch(int dtype, const void* args, int mode, unsigned grid, void* stream);
 #ifndef MIMO_FF_TAIL4_DEFAULT
 #define MIMO_FF_TAIL4_DEFAULT 1
@@ -706,7 +706,9 @@ static int ff_launch(int dtype, FFArgs& g, int mode, void* stream) {
   const unsigned grid = (unsigned)(npanels < cus ? npanels : cus);
   hipStream_t st = (hipStream_t)stream;
   if (dtype != MIMO_F16 && dtype != MIMO_BF16) return MIMO_EDTYPE;
-  if ((mode == 0 || mode == 2) && tune_env("MIMO_FF_TAIL4", MIMO_FF_TAIL4_DEFAULT)) {
+  // (ff4_kernel also has a feed-forward-only MODE 0 — tools/ff4_variants.py times it — but only its whole-tail form is faster
+  // than this file's kernel: 0.626 against 0.674 ms at M = 196 608; MODE 0 0.526 against 0.515)
+  if (mode == 2 && tune_env("MIMO_FF_TAIL4", MIMO_FF_TAIL4_DEFAULT)) {
     mimo_ff4_launch(dtype, &g, mode, grid, stream);
     MIMO_LAUNCH_CHECK();
     return MIMO_OK;

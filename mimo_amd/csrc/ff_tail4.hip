@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
   constexpr unsigned BIAS_Q = BIAS_OFF / 16;
 
   issue_all();      // W1-region tile 0
+  for (int n = tid; n < 2 * (W2_TILE / 16); n += 256)   // the W2 slices' LDS: finite before the first position multiplies zeros with it
+    smem[(n >= W2_TILE / 16 ? STAGE / 16 - W2_TILE / 16 : 0) + W1_TILE / 16 + n] = make_uint4(0u, 0u, 0u, 0u);
   if constexpr (FF4_DEPHASE > 0) {
     if ((blockIdx.x >> 3) & 1u) {
       const unsigned long long t0 = __builtin_readcyclecounter();
@@ -525,38 +527,13 @@ __global__ __launch_bounds__(256, 1) void ff4_kernel(const FFArgs g) {
     u32x2 hA[2], hB[2];          // the previous chunk, packed: pair 0 / pair 1, per row tile
     f32x4 cv, cg, cbv, cbg;      // pair 1, rows 16..31 of the previous chunk and its b1 values: that GEGLU unit runs under the
                                  // next position's first segments
-    // first position of the feed-forward: no previous chunk (segments 0..19, the GEGLU of pair 0 / rows 0..15 under pair 1)
-    {
-      FF_TRACE(g, tr, 18);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      FF_TRACE(g, tr, 19);
-      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
-      issue_begin();
-      uint4 fr[3][2];
-      const uint4 hf0[2] = {};
-      frag_load(ICf<0>{}, sq, 0u, fr[0]);
-      frag_load(ICf<1>{}, sq, 0u, fr[1]);
-      GU u2, u3, u4;
-      const f32x4 bv0 = bias_val(0u, 0), bg0 = bias_gate(0u, 0);
-      cbv = bias_val(0u, 1); cbg = bias_gate(0u, 1);
-      static_for<0, 20>([&](auto seg_c) {
-        constexpr int seg = decltype(seg_c)::value;
-        if constexpr (seg + 2 < 20) frag_load(ICf<seg + 2>{}, sq, 0u, fr[(seg + 2) % 3]);
-        if constexpr (seg < 10) issue_w1(seg_c);
-        else if constexpr ((seg & 1) != 0) issue_w2(ICf<(seg - 10) / 2>{});
-        seg_mma(seg_c, fr[seg % 3], hf0, seg < 10 ? bv0 : cbv, seg < 10 ? bg0 : cbg);
-        if constexpr (seg >= 10) gu_stage(u2, ICf<seg - 10>{}, acc1[0][0], acc1[1][0], bv0, bg0);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      issue_end();
-      gu_all(u3, acc1[0][1], acc1[1][1], bv0, bg0);
-      gu_all(u4, acc1[2][0], acc1[3][0], cbv, cbg);
-      hA[0] = u2.out; hA[1] = u3.out; hB[0] = u4.out;
-      cv = acc1[2][1]; cg = acc1[3][1];
-      ++t;
-    }
+    // The first position has no previous chunk: it runs the same code on an all-zero one (zero hidden values times the finite
+    // contents of the W2 stage — zero-filled at kernel start, stale weights later — add exactly nothing to the accumulators).
+    hA[0] = hA[1] = hB[0] = hB[1] = (u32x2){0u, 0u};
+    cv = cg = cbv = cbg = zero4;
+    FF_TRACE(g, tr, 18);
 #pragma unroll 1
-    for (unsigned j = 1; j < (unsigned)NSTEP; ++j, ++t) {
+    for (unsigned j = 0; j < (unsigned)NSTEP; ++j, ++t) {
       if constexpr ((FF4_ABLATE & 16) == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       FF_TRACE(g, tr, 1);
       const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);

@@ -29,6 +29,7 @@ VARIANTS = [
     ("abl_no_stores", ["-DFF4_ABLATE=64"]),
     ("abl_no_io", ["-DFF4_ABLATE=96"]),
     ("exact", ["-DFF4_TRICKLE=0"]),
+    ("dephase40", ["-DFF4_DEPHASE=40"]),
     ("dephase60", ["-DFF4_DEPHASE=60"]),
     ("dephase100", ["-DFF4_DEPHASE=100"]),
     ("dephase140", ["-DFF4_DEPHASE=140"]),
