@@ -298,7 +298,9 @@ int mimo_ff_proj_fused(int dtype, const void* A, int64_t lda, const void* W1, co
  *   O: half16 attention output; Wstream: half16 [10 C, C] = [Wo with rows in tile order (pack_rows_tail) | W1 GEGLU-packed
  *   with its K axis permuted (pack_ff2_kperm) | Wp as for mimo_ff_proj_fused] (mimo_amd.packing.pack_block_tail_stream);
  *   y and n never reach memory.  img_bias: fp32 [ceil(M / rows_per_img), ldib] or NULL, rows_per_img >= 128.
- *   colstats: as for mimo_ff_proj_fused.  MIMO_EINVAL unless C == 320. */
+ *   colstats: as for mimo_ff_proj_fused.  MIMO_EINVAL unless C == 320.
+ *   Kernel: ff4_kernel (csrc/ff_tail4.hip, four waves x 512 registers); it evaluates the two residual sums as (o Wo^T + bo + img_bias)
+ *   + residual and (z Wp^T + bp) + x — the same numbers in a different fp32 order than written above. */
 int mimo_block_tail_fused(int dtype, const void* O, int64_t ldo_in, const void* Wstream, const float* bo,
                           const float* img_bias, int64_t ldib, int64_t rows_per_img, const float* residual, int64_t ldr,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, const float* b1, const void* W2,
