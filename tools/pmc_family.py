@@ -9,7 +9,7 @@ import sys
 
 def family(k):
     k = re.sub(r"\(anonymous namespace\)::", "", k)
-    for name in ("hconv_kernel", "gemm8_kernel", "thin_conv_kernel", "ff_fused_kernel", "gemm_stream_kernel", "gemm_dense_persist_kernel", "splitk_reduce_kernel",
+    for name in ("hconv_kernel", "gemm8_kernel", "thin_conv_kernel", "ff_fused_kernel", "ff4_kernel", "gemm_stream_kernel", "gemm_dense_persist_kernel", "splitk_reduce_kernel",
                  "attn40_kernel", "temporal_attn2_kernel", "temporal_attn_kernel",
                  "attn_kernel", "gn_apply_kernel", "gn_stats", "layer_norm_kernel"):
         if name in k:
