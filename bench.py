@@ -154,7 +154,9 @@ def pmc_traffic(family):
             full = json.load(open(path))
             return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
                     "write": d["write_bytes_per_launch"], "source": "profiles/" + name,
-                    "library_sha256_16": full.get("library_sha256_16"), "library_sha256_16_now": lib_hash()}
+                    "library_sha256_16": full.get("library_sha256_16"), "library_sha256_16_now": lib_hash(),
+                    "note": "summaries written before the end of round 5 are means over the family's launches OTHER than gemm8_kernel "
+                            "(the tool's name match missed it: DESIGN.md section 5); compare with care"}
         except Exception:
             continue
     return None
