@@ -1,23 +1,29 @@
-// ff_tail4.hip — the fused tail of a C = 320 transformer block (ff_fused.hip, MODE 0 and MODE 2) on FOUR waves, one per SIMD,
-// each with the whole 512-entry register file (gfx950).  Same entry points, same packed weights, same arithmetic in the same
-// order as ff_fused_kernel — the outputs are bit-identical — but a different machine mapping:
+// ff_tail4.hip — the fused tail of a C = 320 transformer block (mimo_block_tail_fused: ff_fused.hip's MODE 2; MODE 0 exists for the
+// variant builds) on FOUR waves, one per SIMD, each with the whole 512-entry register file (gfx950).  Same entry point, same packed
+// weights, same arithmetic as ff_fused_kernel, a different machine mapping:
 //
 //   ff_fused_kernel (8 waves x 256 registers): the two waves of a SIMD share 32 rows and split the 320 columns; every hidden
-//   chunk, every LayerNorm statistic and every re-used accumulator tile crosses between them through LDS behind barriers, and
-//   the measured step (5 070 cycles per 128 rows and 32 hidden columns, r5_block_head_phase_trace / NOTEBOOK round 5 §7, §11)
-//   is MFMA time PLUS the GEGLU's VALU time PLUS DMA issue: the matrix pipe and the VALU of a SIMD do not overlap across waves
-//   (r5_mfma_ceiling.txt, last table).
+//   chunk, every LayerNorm statistic and every re-used accumulator tile crosses between them through LDS behind barriers.
 //
 //   ff4_kernel (this file): wave w owns rows [32 w, 32 w + 32) of the 128-row panel and ALL 320 columns: 160 accumulator
 //   registers (the compiler places them in AGPRs) + 80 operand registers + 32 FF1 accumulators.  Nothing is exchanged: the
-//   GEGLU chunk, the LayerNorm operand and the projection operand go from accumulator to MFMA operand inside the wave.  Every
-//   W fragment read from LDS feeds two MFMAs of the same wave as before, but is read by 4 waves instead of 8.  The only
-//   overlap a single wave has is VALU / LDS / DMA issue in the shadow of its OWN MFMAs (about two issue slots per 16-cycle
-//   MFMA, MI355X_MICROARCH.md "one wave per SIMD"), so the feed-forward is software-pipelined by hand:
-//       step j:   FF1(j, value/gate pair 0)  |  FF1(j, pair 1)  |  FF2(j - 1)          <- 120 MFMAs, back to back
-//                 GEGLU(j - 1, pair 1, rows 16..31)  GEGLU(j, pair 0)  GEGLU(j, pair 1, rows 0..15)   <- VALU in their shadow
-//   (in fenced SEGMENTS of four MFMAs with one stage of the GEGLU polynomial each, W fragments fetched two segments ahead),
-//   and the 15 LDS-DMA pieces a wave issues per step are spread over the first 20 segments instead of going out in one burst.
+//   GEGLU chunk, the LayerNorm operand and the projection operand go from accumulator to MFMA operand inside the wave; the only
+//   barrier is the one per stream position.
+//
+// What was measured on it (NOTEBOOK.md round 5 §13, profiles/r5_ff4_*):
+//   * a 16-cycle 16x16x32 MFMA hides NONE of its own wave's VALU / LDS / DMA instructions (a feed-forward position costs
+//     120 x 16 + 4 x the other instructions), exactly as two waves per SIMD hide none of each other's: the feed-forward is
+//     written as fenced SEGMENTS of four MFMAs with one stage of the GEGLU polynomial each (so the order is mine, not the
+//     scheduler's), but what counts is the instruction count: a DMA piece is three instructions, W fragments are fetched two
+//     segments ahead;
+//   * a third of a panel's time used to be HBM bursts: all 256 persistent blocks reach the panel boundary together.  With
+//     FF4_TRICKLE (shipped) the fp32 operands are added BEHIND the projections they used to initialise, fetched eight loads per
+//     projection tile behind that tile's DMA pieces (at most three column-tile groups in flight), a projection tile's
+//     accumulators are born inside the tile, a finished column-tile group is stored under the next tile, and the next panel's
+//     half operand is fetched under the last tile.  vmcnt is ONE in-order counter for loads, stores and DMA pieces: every
+//     position barrier below waits with the COUNT of what this wave issued behind the pieces it is about to read — keep the
+//     issue order (pieces, then the hook's loads, then the tail hook's stores) when touching the projection code.
+//   FF4_TRICKLE = 0 keeps ff_fused_kernel's operand order and is bit-identical to it (tools/ff4_variants.py, `exact`).
 //
 // Stream protocol (positions, 2-deep ring, one barrier per position, W2 slice one position behind its W1 tile) is the one of
 // ff_fused.hip; the weight tensors are the ones mimo_amd.packing already makes.
