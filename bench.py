@@ -155,8 +155,8 @@ def pmc_traffic(family):
             return {"bytes_per_launch": d["traffic_bytes_per_launch"], "fetch": d["fetch_bytes_per_launch"],
                     "write": d["write_bytes_per_launch"], "source": "profiles/" + name,
                     "library_sha256_16": full.get("library_sha256_16"), "library_sha256_16_now": lib_hash(),
-                    "note": "summaries written before the end of round 5 are means over the family's launches OTHER than gemm8_kernel "
-                            "(the tool's name match missed it: DESIGN.md section 5); compare with care"}
+                    "note": "family = every kernel bench.py brackets as gemm_kernel; summaries stamped with a library older than "
+                            "b95d744fdbf16a78 missed gemm8_kernel (DESIGN.md section 5)"}
         except Exception:
             continue
     return None
