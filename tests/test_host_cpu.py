@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
     assert cdll.mimo_version() >= 1
 
 
+def test_build_compiles_every_hip_source():
+    """Every .hip file under csrc/ is in build.SOURCES and every internal header in its dependency list: a kernel file that is
+    not listed would silently be missing from libmimo_hip.so (and from the driver's build check)."""
+    from mimo_amd import build
+    csrc = os.path.join(ROOT, "mimo_amd", "csrc")
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == sorted(build.SOURCES)
+    src = open(os.path.join(ROOT, "mimo_amd", "build.py")).read()
+    for h in (f for f in os.listdir(csrc) if f.endswith(".hip.h")):
+        assert f'"{h}"' in src, h
+    assert set(build.EXTRA_FLAGS) <= set(build.SOURCES)
+
+
 def test_ops_fail_loudly_without_gpu():
     from mimo_amd import lib, ops
     if torch.cuda.is_available():
