@@ -684,6 +684,45 @@ def test_video_io_round_trips_and_frame_selection(tmp_path):
         V.read_frames(str(tmp_path / "missing.mp4"))
 
 
+def test_video_io_avi_mjpeg_and_raw(tmp_path):
+    """mimo_amd.video_io AVI: uncompressed 24-bit frames round-trip bit for bit (odd widths: padded rows), Motion-JPEG frames come
+    back within JPEG error; frame rate (integer and 29.97), RIFF sizes, index entries and the frame selection hold; a foreign codec
+    fails loudly."""
+    import struct
+    import numpy as np
+    from mimo_amd import video_io as V
+    from mimo_amd.run_edit import keep_frame_indices
+    for w, h in ((40, 24), (37, 23)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames = [np.stack([(xx * 5 + 9 * i) % 256, (yy * 7 + 3 * i) % 256, ((xx + yy) * 3 + i) % 256], -1).astype(np.uint8) for i in range(9)]
+        out = V.save_video(frames, str(tmp_path / f"raw{w}.avi"), fps=25, codec="raw")
+        back, fps = V.read_frames(out)
+        assert fps == 25.0 and len(back) == 9 and all(np.array_equal(np.asarray(b), f) for b, f in zip(back, frames))
+        sel = V.load_video_fixed_fps(out, target_fps=10)
+        idx = keep_frame_indices(9, 25.0, 10)
+        assert len(sel) == len(idx) and all(np.array_equal(np.asarray(a), frames[i]) for a, i in zip(sel, idx))
+        out = V.save_video(frames, str(tmp_path / f"mj{w}.avi"), fps=29.97)
+        back, fps = V.read_frames(out)
+        assert abs(fps - 29.97) < 1e-6 and len(back) == 9
+        assert max(float(np.abs(np.asarray(b).astype(int) - f.astype(int)).mean()) for b, f in zip(back, frames)) < 4.0
+        raw = open(out, "rb").read()
+        assert raw[:4] == b"RIFF" and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8 and raw[8:12] == b"AVI "
+        i = raw.rindex(b"idx1")
+        n = struct.unpack("<I", raw[i + 4:i + 8])[0]
+        assert n == 9 * 16
+        movi = raw.index(b"movi")
+        for k in range(9):   # every index entry points at a '00dc' chunk of the recorded size that starts with a JPEG SOI
+            ck, _, off, size = struct.unpack("<4sIII", raw[i + 8 + 16 * k:i + 24 + 16 * k])
+            assert ck == b"00dc" and raw[movi + off:movi + off + 4] == b"00dc"
+            assert struct.unpack("<I", raw[movi + off + 4:movi + off + 8])[0] == size and raw[movi + off + 8:movi + off + 10] == b"\xff\xd8"
+    bad = bytearray(open(str(tmp_path / "mj40.avi"), "rb").read())
+    j = bad.index(b"strf") + 8 + 16
+    bad[j:j + 4] = b"H264"
+    (tmp_path / "foreign.avi").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError):
+        V.read_frames(str(tmp_path / "foreign.avi"))
+
+
 def test_run_edit_frame_selection_known_answers():
     """run_edit.keep_frame_indices / time_crop_range: the codec-free arithmetic of load_video_fixed_fps
     (tools/util.py:462-479) and of the time crop (run_edit.py:194-198)."""
