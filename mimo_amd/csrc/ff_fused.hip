@@ -708,7 +708,12 @@ static int ff_launch(int dtype, FFArgs& g, int mode, void* stream) {
   if (dtype != MIMO_F16 && dtype != MIMO_BF16) return MIMO_EDTYPE;
   // (ff4_kernel also has a feed-forward-only MODE 0 — tools/ff4_variants.py times it — but only its whole-tail form is faster
   // than this file's kernel: 0.626 against 0.674 ms at M = 196 608; MODE 0 0.526 against 0.515)
-  if (mode == 2 && tune_env("MIMO_FF_TAIL4", MIMO_FF_TAIL4_DEFAULT)) {
+#ifdef MIMO_FF_TAIL4_MODE0   // the variant builds of tools/ff4_variants.py time ff4_kernel's MODE 0 through mimo_ff_fused as well
+  const bool ff4_mode0 = mode == 0;
+#else
+  const bool ff4_mode0 = false;
+#endif
+  if ((mode == 2 || ff4_mode0) && tune_env("MIMO_FF_TAIL4", MIMO_FF_TAIL4_DEFAULT)) {
     mimo_ff4_launch(dtype, &g, mode, grid, stream);
     MIMO_LAUNCH_CHECK();
     return MIMO_OK;

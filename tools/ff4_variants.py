@@ -54,7 +54,7 @@ def build(names):
         objs[d] = os.path.join(VDIR, f"ff_fused_d{d}.o")
         src = os.path.join(CSRC, "ff_fused.hip")
         if not os.path.exists(objs[d]) or os.path.getmtime(objs[d]) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "ff_fused.hip.h"))):
-            r = subprocess.run(HIPCC + [f"-DMIMO_FF_TAIL4_DEFAULT={d}", "-c", src, "-o", objs[d]], capture_output=True, text=True)
+            r = subprocess.run(HIPCC + [f"-DMIMO_FF_TAIL4_DEFAULT={d}", "-DMIMO_FF_TAIL4_MODE0", "-c", src, "-o", objs[d]], capture_output=True, text=True)
             if r.returncode:
                 raise RuntimeError(r.stderr[-3000:])
 
