@@ -122,7 +122,10 @@ typedef struct mimo_epilogue_ext {
   float a_eps;
 } mimo_epilogue_ext;
 
-/* number of column slots of row_stats for a producer of width N (0: the folded form does not cover N) */
+/* number of column slots of row_stats for a producer of width N (0: the folded form does not cover N).  Covered: N a whole
+ * number of the producer family's widest tile (N % 256 == 0 with 64-column slots, N % 320 == 0 with 80-column slots: the row-side
+ * epilogue has no column mask) and at most 20 slots (what a consumer row holds) — 640 -> 8, 1280 -> 20; 960, 1920, 2560 -> 0.
+ * A consumer's a_slots must equal mimo_row_stat_slots(K); anything else is MIMO_EINVAL. */
 int mimo_row_stat_slots(int N);
 
 int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* W, void* out, int64_t ldo,
@@ -209,6 +212,15 @@ int mimo_group_norm_stats_slabs(const float* cs1, int C1, int rows_per_slab1, co
 int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_is_f32, int dtype,
                           int n, int64_t HW, int groups, const float* stats, const float* gamma,
                           const float* beta, int silu, void* out, void* raw_out, void* stream);
+/* Split-operand apply pass (the VAE's "split" precision policy; diffusers AutoencoderKL.encode as called at
+ * src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py:427-439, whose fp32 result the 1e-3 parity bar is measured
+ * against): y = GroupNorm(x) (+ SiLU) — or y = x when stats == NULL — of an fp32 tensor x [n, HW, C] is stored as THREE
+ * half16 channel blocks per token, out[tok][0..C) = out[tok][C..2C) = hi = half(y), out[tok][2C..3C) = lo = half(y - hi);
+ * row stride ldo >= 3 C elements (columns beyond 3 C are left untouched: the caller zero-fills padding once).  Multiplied by a
+ * weight packed [Whi | Wlo | Whi] along K by the ordinary mimo_gemm / mimo_conv2d the fp32 accumulators receive
+ * hi.Whi + hi.Wlo + lo.Whi: both operands carry ~22 mantissa bits.  C % 8 == 0, ldo % 8 == 0, 16-byte aligned pointers. */
+int mimo_group_norm_apply_split3(const float* x, int C, int dtype, int n, int64_t HW, int groups, const float* stats,
+                                 const float* gamma, const float* beta, int silu, void* out, int64_t ldo, void* stream);
 /* GroupNorm folded to a per-(image, channel) affine: ab fp32 [n][2][C], ab[i][0][c] = rstd(i, g(c)) * gamma[c],
  * ab[i][1][c] = beta[c] - mean(i, g(c)) * ab[i][0][c], so that GroupNorm(x)[c] = x * a + b.  The operand of
  * mimo_conv3x3_fused (the apply pass of src/models/resnet.py:20-28,220-221,237 without a pass over the tensor). */
@@ -397,10 +409,24 @@ int mimo_cast(const void* in, int in_is_f32, int dtype, int64_t count, void* out
 int mimo_cfg_ddim_step(const float* acc, const float* counter, float* latents, int C, int F,
                        int64_t HW, int cfg, float guidance, float sqrt_a_t, float sqrt_1ma_t,
                        float sqrt_a_prev, float sqrt_1ma_prev, void* stream);
+/* The same update for the listed frames only (frames: int32 [nf] device, distinct, each in [0, F)); per element the
+ * arithmetic of mimo_cfg_ddim_step bit for bit.  The sharded long clip's cross-step schedule advances a frame from step t
+ * to t + 1 as soon as every context window that covers it (src/pipelines/context.py:15-42) has delivered its step-t
+ * prediction — the reference's loop (:505-553) has no dependency between frames that share no window. */
+int mimo_cfg_ddim_step_frames(const float* acc, const float* counter, float* latents, int C, int F, int64_t HW,
+                              const int* frames, int nf, int cfg, float guidance, float sqrt_a_t, float sqrt_1ma_t,
+                              float sqrt_a_prev, float sqrt_1ma_prev, void* stream);
 /* acc[:, :, frames[j]] += pred[:, :, j]; counter[frames[j]] += 1, with pred given as the UNet's
- * token-major output fp32 [bb*Fw, HW, ld] (channels [0,C)); frames: int32 [Fw] device. */
+ * token-major output fp32 [bb*Fw, HW, ld] (channels [0,C)); frames: int32 [Fw] device; frames[j] < 0: row j of the
+ * prediction is skipped (only a frame segment of the window is taken). */
 int mimo_window_accumulate(const float* pred, int64_t ld, const int* frames, int Fw, int bb, int C,
                            int F, int64_t HW, float* acc, float* counter, void* stream);
+
+/* differ[i] = 1 where frame i of `frames` ([n] frames of frame_bytes bytes each, any element type, frame_bytes % 16 == 0)
+ * is not bit-identical to frame i - 1; differ[0] = 1.  The caller zero-fills differ[1..n) first (int32 [n] device).
+ * run_animate.py feeds the VAE encoder F copies of ONE background frame (tools/util.py:339-345 `init_bk`, encoded one by
+ * one at pipeline :436-443): the encoder runs once per run of identical frames. */
+int mimo_frames_differ(const void* frames, int n, int64_t frame_bytes, int* differ, void* stream);
 
 /* VAE image post-process: tokens half16/fp32 [n, H*W, ld] (3 ch) -> fp32 [n,3,H,W] = clamp(x/2+0.5,0,1)
  *   (src/pipelines/pipeline_pose2vid_long_edit_bkfill_roiclip.py:123) */

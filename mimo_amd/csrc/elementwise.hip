@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void window_accumulate_kernel(const float* pre
     const int c = (int)(r % C);
     const int bi = (int)(r / C);
     const int f = frames[j];
+    if (f < 0) continue;  // frame not taken from this prediction (a frame segment of the window only, see the header)
     acc[(((int64_t)bi * C + c) * F + f) * HW + p] += pred[(((int64_t)bi * Fw + j) * HW + p) * ld + c];
   }
-  if (blockIdx.x == 0 && threadIdx.x < Fw) counter[frames[threadIdx.x]] += 1.f;
+  if (blockIdx.x == 0 && threadIdx.x < Fw && frames[threadIdx.x] >= 0) counter[frames[threadIdx.x]] += 1.f;
 }
 
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* acc, const float* counter, float* lat, int C,
@@ -106,6 +107,50 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* acc, const f
     const float eps = sa * np + s1 * x;
     lat[i] = sap * x0 + s1p * eps;
   }
+}
+
+// The same update restricted to a list of frames (the cross-step schedule of the sharded long clip advances a frame as soon as
+// every window that covers it has delivered its prediction; per element the arithmetic is cfg_ddim_kernel's, bit for bit).
+__global__ __launch_bounds__(256) void cfg_ddim_frames_kernel(const float* acc, const float* counter, float* lat, int C,
+                                                              int F, int64_t HW, const int* frames, int nf, int cfg,
+                                                              float guidance, float sa, float s1, float sap, float s1p) {
+  const int64_t total = (int64_t)C * nf * HW;
+  const int64_t plane = (int64_t)C * F * HW;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+    const int64_t p = j % HW;
+    const int64_t r = j / HW;
+    const int f = frames[(int)(r % nf)];
+    const int c = (int)(r / nf);
+    const int64_t i = ((int64_t)c * F + f) * HW + p;
+    float np;
+    if (cfg) {
+      const float cnt = counter[f];
+      const float un = acc[i] / cnt;
+      const float co = acc[plane + i] / cnt;
+      np = un + guidance * (co - un);
+    } else {
+      np = acc[i];
+    }
+    const float x = lat[i];
+    const float x0 = sa * x - s1 * np;
+    const float eps = sa * np + s1 * x;
+    lat[i] = sap * x0 + s1p * eps;
+  }
+}
+
+// differ[i] = 1 where frame i is not bit-identical to frame i - 1 (differ[0] = 1): 16-byte compares, one flag store per
+// block that finds a difference (benign race: every writer stores the same value).  The caller zero-fills differ[1..].
+__global__ __launch_bounds__(256) void frames_differ_kernel(const uint4* x, int64_t vec_per_frame, int blocks_per_frame, int* differ) {
+  const int f = 1 + blockIdx.x / blocks_per_frame, sl = blockIdx.x % blocks_per_frame;
+  if (blockIdx.x == 0 && threadIdx.x == 0) differ[0] = 1;
+  const uint4* a = x + (int64_t)f * vec_per_frame;
+  const uint4* b = a - vec_per_frame;
+  bool d = false;
+  for (int64_t i = (int64_t)sl * 256 + threadIdx.x; i < vec_per_frame; i += (int64_t)blocks_per_frame * 256) {
+    const uint4 u = a[i], v = b[i];
+    d |= (u.x != v.x) | (u.y != v.y) | (u.z != v.z) | (u.w != v.w);
+  }
+  if (__any(d) && (threadIdx.x & 63) == 0) differ[f] = 1;
 }
 
 // Second half of a thin-output 3x3 convolution (Cout <= 16: conv_out of the UNet and of the VAE decoder).  The first half is a
@@ -220,6 +265,34 @@ extern "C" int mimo_cfg_ddim_step(const float* acc, const float* counter, float*
   if (!acc || !counter || !latents || C <= 0 || F <= 0 || HW <= 0) return MIMO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_grid((int64_t)C * F * HW)), dim3(256), 0, st, acc, counter, latents, C, F, HW, cfg, guidance, sqrt_a_t, sqrt_1ma_t, sqrt_a_prev, sqrt_1ma_prev);
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_cfg_ddim_step_frames(const float* acc, const float* counter, float* latents, int C, int F, int64_t HW,
+                                         const int* frames, int nf, int cfg, float guidance, float sqrt_a_t, float sqrt_1ma_t,
+                                         float sqrt_a_prev, float sqrt_1ma_prev, void* stream) {
+  if (!acc || !counter || !latents || !frames || C <= 0 || F <= 0 || HW <= 0 || nf <= 0 || nf > F) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cfg_ddim_frames_kernel, dim3(ew_grid((int64_t)C * nf * HW)), dim3(256), 0, st, acc, counter, latents, C, F, HW,
+                     frames, nf, cfg, guidance, sqrt_a_t, sqrt_1ma_t, sqrt_a_prev, sqrt_1ma_prev);
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_frames_differ(const void* frames, int n, int64_t frame_bytes, int* differ, void* stream) {
+  if (!frames || !differ || n <= 0 || frame_bytes <= 0 || (frame_bytes & 15) || (reinterpret_cast<uintptr_t>(frames) & 15u)) return MIMO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 1) {
+    hipLaunchKernelGGL(frames_differ_kernel, dim3(1), dim3(64), 0, st, (const uint4*)frames, (int64_t)0, 1, differ);
+    MIMO_LAUNCH_CHECK();
+    return MIMO_OK;
+  }
+  const int64_t vec = frame_bytes / 16;
+  int bpf = (int)((vec + 256 * 16 - 1) / (256 * 16));   // >= 16 vectors per thread
+  if (bpf < 1) bpf = 1;
+  if (bpf > 256) bpf = 256;
+  hipLaunchKernelGGL(frames_differ_kernel, dim3((unsigned)((n - 1) * bpf)), dim3(256), 0, st, (const uint4*)frames, vec, bpf, differ);
   MIMO_LAUNCH_CHECK();
   return MIMO_OK;
 }

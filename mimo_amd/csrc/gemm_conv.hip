@@ -1859,6 +1859,17 @@ int row_slot_width(int N) {
   return N % 64 == 0 ? 64 : 0;
 }
 
+// Slots per row of a folded LayerNorm of width N, or 0 where the fold does not apply: the producer's row-side epilogue has no
+// column mask, so N must be a whole number of the WIDEST tile its kernel family uses (4 slots: 256 columns for the 64-wide
+// slots, 320 for the 80-wide ones — 480 / 800 / 960 / 1920 would let a wave past column N write into the next row); the
+// consumer holds at most 2 * ROW_STAT_LOADS slots (N = 2560 has 40).
+int row_stat_slots_of(int N) {
+  const int w = N > 0 ? row_slot_width(N) : 0;
+  if (!w || N % (4 * w) != 0) return 0;
+  const int slots = N / w;
+  return (slots & 1) == 0 && slots <= 2 * ROW_STAT_LOADS ? slots : 0;
+}
+
 template <int DT, int MODE>
 int launch(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
@@ -1886,20 +1897,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-static int check_ext(const mimo_epilogue_ext* e, GemmArgs& g, int64_t M, int N, unsigned flags) {
+static int check_ext(const mimo_epilogue_ext* e, GemmArgs& g, int64_t M, int N, int K, unsigned flags) {
   g.colstats = nullptr; g.ln_gamma = g.ln_beta = g.ln_pe = nullptr; g.ln_out = nullptr;
   g.ln_eps = 0.f; g.ln_rows_per_frame = 1; g.ln_pe_frames = 1;
   g.row_half = nullptr; g.row_stats = nullptr; g.a_row_stats = nullptr; g.a_colsum = nullptr; g.a_slots = 0; g.a_eps = 0.f;
   if (!e) return MIMO_OK;
   if (e->row_half || e->row_stats) {   // producer half of a folded LayerNorm: fp32 result + half copy + row statistics
     if (!e->row_half || !e->row_stats || e->colstats || e->ln_out || !(flags & MIMO_EPI_OUT_F32) ||
-        (flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || row_slot_width(N) == 0 || M >= 0x7fffffffLL / ((int64_t)N * 2) ||
+        (flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || row_stat_slots_of(N) == 0 || M >= 0x7fffffffLL / ((int64_t)N * 2) ||
         !aligned16(e->row_half) || !aligned16(e->row_stats))
       return MIMO_EINVAL;
     g.row_half = e->row_half; g.row_stats = e->row_stats;
   }
   if (e->a_row_stats || e->a_colsum) {  // consumer half
-    if (!e->a_row_stats || !e->a_colsum || e->a_slots <= 0 || (e->a_slots & 1) || e->a_slots > 2 * ROW_STAT_LOADS || e->colstats || e->ln_out ||
+    // (a_slots must be the producer's slot count for THIS K: statistics of another width would be read misaligned)
+    if (!e->a_row_stats || !e->a_colsum || e->a_slots <= 0 || e->a_slots != row_stat_slots_of(K) || e->colstats || e->ln_out ||
         M >= 0x7fffffffLL / ((int64_t)e->a_slots * 8) || !aligned16(e->a_row_stats) || !aligned16(e->a_colsum))
       return MIMO_EINVAL;
     g.a_row_stats = e->a_row_stats; g.a_colsum = e->a_colsum; g.a_slots = e->a_slots; g.a_eps = e->a_eps;
@@ -1939,7 +1951,7 @@ extern "C" int mimo_gemm_ext(int dtype, const void* A, int64_t lda, const void* 
   g.N = N; g.K = K; g.out_scale = out_scale; g.flags = flags;
   g.ws = aligned16(workspace) ? workspace : nullptr; g.ws_bytes = workspace_bytes;
   g.nkt = (K + BK - 1) / BK;
-  if (int rc = check_ext(ext, g, M, N, flags)) return rc;
+  if (int rc = check_ext(ext, g, M, N, K, flags)) return rc;
   if (g.ln_out && ((flags & (MIMO_EPI_SILU | MIMO_EPI_GEGLU)) || ldo != N || (residual && ldr != N))) return MIMO_EINVAL;
   const int64_t ab = ((M - 1) * lda + K) * 2, wb = (int64_t)N * K * 2;
   if (ab >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // 32-bit offsets; 2 GiB keeps OOBA + soffset out of range
@@ -2021,7 +2033,7 @@ extern "C" int mimo_conv2d_ext(int dtype, const void* in, const void* in2, const
   g.chunks1 = (p->Cin + BK - 1) / BK;
   g.chunks2 = (p->Cin2 + BK - 1) / BK;
   g.nkt = p->ksize * p->ksize * g.chunks1 + g.chunks2;
-  if (int rc = check_ext(ext, g, g.M, g.N, flags)) return rc;
+  if (int rc = check_ext(ext, g, g.M, g.N, g.K, flags)) return rc;
   {
     const int64_t ab = (int64_t)p->n * p->Hin * p->Win * p->Cin * 2, a2b = g.M * p->Cin2 * 2, wb = (int64_t)g.N * g.K * 2;
     if (ab >= 0x80000000LL || a2b >= 0x80000000LL || wb >= 0x80000000LL) return MIMO_EINVAL;  // see OOBA
@@ -2042,10 +2054,7 @@ extern "C" int mimo_conv2d(int dtype, const void* in, const void* in2, const voi
                          workspace_bytes, nullptr, stream);
 }
 
-extern "C" int mimo_row_stat_slots(int N) {
-  const int w = N > 0 ? row_slot_width(N) : 0;
-  return w ? N / w : 0;
-}
+extern "C" int mimo_row_stat_slots(int N) { return row_stat_slots_of(N); }
 
 extern "C" int mimo_version(void) { return 5; }
 

@@ -317,6 +317,51 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, int C1, c
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Split-operand form of the apply pass (the VAE's "split" precision policy): y = silu?(GroupNorm(x)) (or y = x without
+// statistics) is written as THREE half16 channel blocks per token, [hi | hi | lo] with hi = half(y), lo = half(y - hi).
+// Against a weight packed as [Whi | Wlo | Whi] along K (packing.pack_conv_split3) one ordinary MFMA GEMM / implicit-GEMM
+// convolution then sums hi.Whi + hi.Wlo + lo.Whi in its fp32 accumulators: both operands carry ~22 mantissa bits, the
+// dropped lo.Wlo term is 2^-22 of the result.  Each thread handles 8 consecutive channels of one token.
+// ---------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void gn_apply_split3_kernel(const float* x, int C, int n, int64_t HW, int groups,
+                                                              const float* stats, const float* gamma, const float* beta,
+                                                              int silu, uint16_t* out, int64_t ldo) {
+  const int cpg = C / groups;
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)n * HW * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t tok = i / c8;
+    const int c = (int)(i - tok * c8) * 8;
+    const int img = (int)(tok / HW);
+    float v[8];
+    const float4 a = *reinterpret_cast<const float4*>(x + tok * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(x + tok * C + c + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    if (stats) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int grp = (c + k) / cpg;
+        const float mean = stats[((int64_t)img * groups + grp) * 2];
+        const float rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
+        const float t = (v[k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        v[k] = silu ? silu_f(t) : t;
+      }
+    }
+    float lo[8];
+    const uint4 hi = pack8<DT>(v);
+    float hf[8];
+    unpack8<DT>(hi, hf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo[k] = v[k] - hf[k];
+    uint16_t* o = out + tok * ldo + c;
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + C) = hi;
+    *reinterpret_cast<uint4*>(o + 2 * C) = pack8<DT>(lo);
+  }
+}
+
 // GroupNorm folded to y = x * a + b per (image, channel): the operand of mimo_conv3x3_fused (hconv.hip)
 __global__ __launch_bounds__(256) void gn_affine_kernel(const float* stats, const float* gamma, const float* beta, int n, int C,
                                                         int groups, float* ab) {
@@ -543,6 +588,24 @@ extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int
     hipLaunchKernelGGL(gn_apply_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, (uint16_t*)raw_out);
   else if (dtype == MIMO_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x1, C1, x2, C2, x_is_f32, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, (uint16_t*)raw_out);
+  else
+    return MIMO_EDTYPE;
+  MIMO_LAUNCH_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_group_norm_apply_split3(const float* x, int C, int dtype, int n, int64_t HW, int groups, const float* stats,
+                                            const float* gamma, const float* beta, int silu, void* out, int64_t ldo, void* stream) {
+  if (!x || !out || n <= 0 || HW <= 0 || C <= 0 || (C & 7) || ldo < 3 * (int64_t)C || (ldo & 7)) return MIMO_EINVAL;
+  if (stats && (!gamma || !beta || groups <= 0 || C % groups)) return MIMO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return MIMO_EINVAL;
+  if (!stats) groups = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = stream_grid((int64_t)n * HW * (C / 8));
+  if (dtype == MIMO_F16)
+    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo);
+  else if (dtype == MIMO_BF16)
+    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo);
   else
     return MIMO_EDTYPE;
   MIMO_LAUNCH_CHECK();

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mimo_group_norm_stats_slabs": [c_vp, c_i, c_i, c_vp, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
+    "mimo_group_norm_apply_split3": [c_vp, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i64, c_vp],
     "mimo_group_norm_affine": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
     "mimo_conv3x3_fused": [c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i64, c_vp, ctypes.POINTER(HconvParams), c_vp, c_vp, c_vp,
                            c_vp, c_vp, c_f, c_u, c_vp],
@@ -80,6 +81,8 @@ SIGNATURES = {
     "mimo_tokens_to_ncfhw": [c_vp, c_i, c_i, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp],
     "mimo_cast": [c_vp, c_i, c_i, c_i64, c_vp, c_vp],
     "mimo_cfg_ddim_step": [c_vp, c_vp, c_vp, c_i, c_i, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_vp],
+    "mimo_cfg_ddim_step_frames": [c_vp, c_vp, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp],
+    "mimo_frames_differ": [c_vp, c_i, c_i64, c_vp, c_vp],
     "mimo_window_accumulate": [c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_i64, c_vp, c_vp, c_vp],
     "mimo_tokens_to_image": [c_vp, c_i, c_i, c_i64, c_i, c_i, c_i, c_vp, c_vp],
     "mimo_resample_pass_u8": [c_vp, c_i, c_i64, c_i64, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_i, c_vp],

@@ -109,6 +109,17 @@ class HipModule(nn.Module):
     def _dev(self):
         return next(self.parameters()).device
 
+    def packed_split(self, dtype, fn):
+        """A second packed-weight cache (same invalidation) for the split-operand precision policy of the VAE (vae.py):
+        fn(dtype) -> dict, built on first use."""
+        key = (dtype, self._dev())
+        cache = self.__dict__.setdefault("_pk_split", {})
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                cache[key] = fn(dtype)
+        return cache[key]
+
     def prepack(self, dtype):
         """Pack every HipModule below (and including) this one NOW, on the current stream.  `packed()` packs lazily on
         whichever stream is current and publishes the cache entry at once; a consumer on ANOTHER stream would then read
@@ -123,6 +134,7 @@ class HipModule(nn.Module):
         _PACK_EPOCH[0] += 1
         for m in self.modules():
             m.__dict__.pop("_pk", None)
+            m.__dict__.pop("_pk_split", None)
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -639,7 +651,7 @@ class MotionModule(HipModule):
             return ops.with_stats(out.view(n, H, W, C), ops.stats_of(out))
         g, _ = ops.group_norm(x, p["g"], p["b"], groups=32, eps=1e-6, silu=False, dtype=ctx.dtype)
         # every LayerNorm (+ positional encoding) rides in the epilogue of the GEMM that produces its input
-        if ops.ln_foldable(C):  # C >= 640: each LayerNorm is folded into the projection that consumes it (ops.LN_FOLD)
+        if ops.ln_foldable(C, n * HW):  # C >= 640: each LayerNorm is folded into the projection that consumes it (ops.LN_FOLD)
             norms = self.temporal_transformer.transformer_blocks[0].norms
             ln = [dict(gamma=p[f"nw{i}"], beta=p[f"nb{i}"], eps=norms[i].eps, fold=True) for i in range(2)]
             ln.append(dict(gamma=p["fnw"], beta=p["fnb"], eps=blk_eps, fold=True))

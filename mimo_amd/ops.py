@@ -238,8 +238,10 @@ def row_stat_slots(N):
     return _SLOTS[N]
 
 
-def ln_foldable(N):
-    return LN_FOLD and N >= LN_FOLD_MIN_C and row_stat_slots(N) > 0 and row_stat_slots(N) % 2 == 0
+def ln_foldable(N, M=0):
+    """The folded LayerNorm covers width N (mimo_row_stat_slots: whole widest tiles, at most 20 slots) and, if given, row count M
+    (the library addresses row_half with 32-bit byte offsets); callers fall back to out + layer_norm otherwise."""
+    return LN_FOLD and N >= LN_FOLD_MIN_C and row_stat_slots(N) > 0 and M < (2 ** 31 - 1) // (2 * N)
 
 
 def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f32=False, silu=False,
@@ -284,7 +286,7 @@ def gemm(a, w, *, bias=None, img_bias=None, rows_per_img=0, residual=None, out_f
     fuse_ln = (ln is not None and (N == 320 or (N == 640 and LN_OUT_640 and K % 32 == 0)) and not geglu and not silu
                and out.stride(0) == N and out.is_contiguous() and (residual is None or ldr == N)
                and (ln.get("pe") is None or (ln.get("rows_per_frame", 0) % 128 == 0 and ln.get("pe_frames", 0) > 0)))
-    fold = (ln is not None and ln.get("fold") and not fuse_ln and ln_foldable(N) and out.dtype == torch.float32 and not geglu
+    fold = (ln is not None and ln.get("fold") and not fuse_ln and ln_foldable(N, M) and out.dtype == torch.float32 and not geglu
             and not silu and ln.get("pe") is None)
     cs = ln_out = row_half = row_stats = None
     if fold:
@@ -587,6 +589,39 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
                             want_norm=want_norm)
 
 
+def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype=torch.float16, ld=None):
+    """The split-operand form of an fp32 activation (mimo_group_norm_apply_split3): half [..., ld >= 3C] = [hi | hi | lo] of
+    y = silu?(GroupNorm(x)) with the given statistics (fp32 [n, groups, 2]) or of x itself (stats None) — the A operand of a
+    GEMM / convolution whose weight is packing.pack_conv_split3 / pack_linear_split3 ([Whi | Wlo | Whi] along K): both
+    operands then carry ~22 mantissa bits through the fp16 MFMAs.  x: fp32 [n, H, W, C] or [M, C]; ld > 3C: zero padding."""
+    _chk(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
+    C = x.shape[-1]
+    n = x.shape[0] if x.dim() == 4 else 1
+    HW = x.numel() // (n * C)
+    ld = 3 * C if ld is None else int(ld)
+    out = (torch.zeros if ld > 3 * C else torch.empty)(tuple(x.shape[:-1]) + (ld,), device=x.device, dtype=dtype)
+    if stats is not None:
+        assert stats.is_contiguous() and stats.shape == (n, groups, 2) and gamma.numel() == C and beta.numel() == C
+    L.call("mimo_group_norm_apply_split3", x.data_ptr(), C, dt_code(dtype), n, HW, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
+           int(silu), out.data_ptr(), ld, _stream())
+    return out
+
+
+def frames_differ(x):
+    """int32 [n] device: 1 where frame i of the contiguous tensor x [n, ...] is not bit-identical to frame i - 1 (entry 0 is 1);
+    None when the frame size is not a multiple of 16 bytes."""
+    _chk(x, "x")
+    assert x.is_contiguous()
+    n = x.shape[0]
+    fb = x.numel() // n * x.element_size()
+    if fb % 16 or x.data_ptr() % 16:
+        return None
+    d = torch.zeros((n,), device=x.device, dtype=torch.int32)
+    L.call("mimo_frames_differ", x.data_ptr(), n, fb, d.data_ptr(), _stream())
+    return d
+
+
 def group_norm_affine(stats, gamma, beta, C, groups=32):
     """GroupNorm folded to a per-(image, channel) affine: fp32 [n, 2, C] with GroupNorm(x)[c] = x * ab[i, 0, c] + ab[i, 1, c]
     (the operand of conv3x3_fused)."""
@@ -845,10 +880,16 @@ def window_accumulate(pred_tok, frames, acc, counter):
            H * W, acc.data_ptr(), counter.data_ptr(), _stream())
 
 
-def cfg_ddim_step(acc, counter, latents, cfg, guidance, sa, s1, sap, s1p):
-    """In-place: latents <- DDIM(v-pred) step of CFG-combined, window-averaged prediction."""
+def cfg_ddim_step(acc, counter, latents, cfg, guidance, sa, s1, sap, s1p, frames=None):
+    """In-place: latents <- DDIM(v-pred) step of CFG-combined, window-averaged prediction; frames (int32 device tensor of
+    distinct frame indices): only those frames are advanced (same arithmetic per element)."""
     _chk(latents, "latents")
     assert latents.dtype == torch.float32 and latents.is_contiguous() and acc.is_contiguous()
     _, C, F, H, W = latents.shape
+    if frames is not None:
+        assert frames.dtype == torch.int32 and frames.is_contiguous() and 0 < frames.numel() <= F
+        L.call("mimo_cfg_ddim_step_frames", acc.data_ptr(), counter.data_ptr(), latents.data_ptr(), C, F, H * W, frames.data_ptr(),
+               frames.numel(), int(cfg), float(guidance), float(sa), float(s1), float(sap), float(s1p), _stream())
+        return
     L.call("mimo_cfg_ddim_step", acc.data_ptr(), counter.data_ptr(), latents.data_ptr(), C, F, H * W, int(cfg),
            float(guidance), float(sa), float(s1), float(sap), float(s1p), _stream())

@@ -20,6 +20,50 @@ def pack_conv(weight, dtype, shortcut=None, cin_pad=None, cout_pad=None):
     return w.to(dtype).contiguous()
 
 
+def split_hi_lo(w, dtype):
+    """fp32 tensor -> (hi, lo) in `dtype` with hi = round(w), lo = round(w - hi): w = hi + lo to ~22 mantissa bits."""
+    w = w.detach().float()
+    hi = w.to(dtype)
+    return hi, (w - hi.float()).to(dtype)
+
+
+def pack_conv_split3(weight, dtype, shortcut=None, cin_pad=None, cout_pad=None, k_pad=None):
+    """pack_conv for the split-operand policy (ops.split3): every tap's Cin block becomes [Whi | Wlo | Whi] (3 Cin columns),
+    matching an input whose channels are [hi | hi | lo]; the fused 1x1 shortcut segment likewise.  cin_pad pads Cin BEFORE the
+    tripling (the input's channel count), k_pad the tripled per-tap block (a thin first conv: 3 * 8 -> 32 channels)."""
+    co, ci, kh, kw = weight.shape
+    w = weight.detach().float().permute(0, 2, 3, 1)  # [co, kh, kw, ci]
+    if cin_pad is not None and cin_pad > ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+    hi, lo = split_hi_lo(w, dtype)
+    w3 = torch.cat([hi, lo, hi], dim=-1)
+    if k_pad is not None and k_pad > w3.shape[-1]:
+        w3 = torch.nn.functional.pad(w3, (0, k_pad - w3.shape[-1]))
+    w3 = w3.reshape(co, -1)
+    if shortcut is not None:
+        sh, sl = split_hi_lo(shortcut.detach().float().reshape(co, -1), dtype)
+        w3 = torch.cat([w3, sh, sl, sh], dim=1)
+    if cout_pad is not None and cout_pad > co:
+        w3 = torch.nn.functional.pad(w3, (0, 0, 0, cout_pad - co))
+    return w3.contiguous()
+
+
+def pack_linear_split3(weight, dtype, rows_pad=None):
+    """Linear weight [N, K] -> [N (+pad), 3K] = [Whi | Wlo | Whi] for an A operand made by ops.split3."""
+    hi, lo = split_hi_lo(weight.reshape(weight.shape[0], -1), dtype)
+    w3 = torch.cat([hi, lo, hi], dim=1)
+    if rows_pad is not None and rows_pad > w3.shape[0]:
+        w3 = torch.nn.functional.pad(w3, (0, 0, 0, rows_pad - w3.shape[0]))
+    return w3.contiguous()
+
+
+def pack_linear_split2(weight, dtype):
+    """Linear weight [N, K] -> [N, 2K] = [Whi | Wlo] for a half A operand repeated twice along K ([a | a]): only the weight
+    is split (the operand is already a 16-bit tensor, e.g. an attention output)."""
+    hi, lo = split_hi_lo(weight.reshape(weight.shape[0], -1), dtype)
+    return torch.cat([hi, lo], dim=1).contiguous()
+
+
 def pack_conv_taps(weight, dtype, cout_pad=None):
     """nn.Conv2d 3x3 weight [Cout, Cin, 3, 3] -> [9 * Cout(+pad), Cin], row (3 ky + kx) * Cout + c: the weight of the GEMM half
     of a thin-output convolution (ops.conv3x3_thin_out: every pixel's contribution to the nine outputs around it)."""

@@ -335,6 +335,7 @@ class Pose2VideoPipeline:
         self.scheduler = scheduler
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         self.vae_batch = 8  # frames per VAE launch group (bounds activation memory; results are per-image)
+        self.dedup_frames = True  # encode each run of bit-identical consecutive input frames once (see _encode_frames)
         self.dist_group = None
         self.shard_windows = False  # True: deal (window, CFG half) units over the torch.distributed ranks
         self.shard_emulate = None   # (rank, world): run THAT rank's share of a `world`-GPU sharded clip on this one GPU (needs a
@@ -383,31 +384,61 @@ class Pose2VideoPipeline:
     # ------------------------------------------------------------------------------------------
     def _encode_frames(self, images):
         """images [n,3,H,W] in [-1,1] (device), or half tokens [n,H,W,8] from image.vae_preprocess
-        -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443)."""
+        -> fp32 latent tokens [n,h,w,4] * 0.18215 (pipeline :427-443).
+
+        Runs of bit-identical consecutive frames are encoded ONCE (self.dedup_frames): run_animate.py's background is F
+        copies of one frame (tools/util.py:339-345), which the reference encodes F times (:436-443).  One compare kernel
+        and one F-integer read-back decide; the encoder is deterministic per image, so the clip's latents are unchanged."""
         dt = self.vae.compute_dtype
-        outs = []
         from .image import ImageTokens
         tokens_in = isinstance(images, ImageTokens)
         if tokens_in and images.dtype != dt:
             raise ValueError(f"pre-tokenised images are {images.dtype}, the VAE computes in {dt}")
-        nb = min(self.vae_batch, self.vae.max_images(*(images.shape[1:3] if tokens_in else images.shape[-2:])))
-        for i in range(0, images.shape[0], nb):
-            if tokens_in:
-                tok = images[i:i + nb].as_subclass(torch.Tensor).contiguous()
+        n = images.shape[0]
+        plain = images.as_subclass(torch.Tensor) if tokens_in else images
+        index = None
+        if self.dedup_frames and n > 1:
+            diff = ops.frames_differ(plain.contiguous())
+            if diff is not None:
+                starts = [1 if (d or i == 0) else 0 for i, d in enumerate(diff.tolist())]  # 1 = first frame of a run
+                if sum(starts) < n:
+                    run_of, k = [], -1
+                    for s_ in starts:
+                        k += s_
+                        run_of.append(k)
+                    index = torch.tensor(run_of, device=plain.device)
+                    plain = plain[torch.tensor([i for i, s_ in enumerate(starts) if s_], device=plain.device)]
+        split = getattr(self.vae, "encode_precision", "half") == "split"
+        hw = plain.shape[1:3] if tokens_in else plain.shape[-2:]
+        nb = min(self.vae_batch, self.vae.max_images(*hw, split=split) if split else self.vae.max_images(*hw))
+        outs = []
+        for i in range(0, plain.shape[0], nb):
+            chunk = plain[i:i + nb]
+            if split:
+                from .vae import nchw_to_tokens32
+                # (pre-tokenised half input carries no low part: the image was rounded when it was tokenised)
+                x32 = chunk.float().contiguous() if tokens_in else nchw_to_tokens32(chunk)
+                outs.append(self.vae.encode_tokens_split(x32))
             else:
-                tok = ops.ncfhw_to_tokens(images[i:i + nb].float().contiguous()[:, :, None], dt, cpad=8)
-            outs.append(self.vae.encode_tokens(tok))
-        return torch.cat(outs) * VAE_SCALE
+                tok = chunk.contiguous() if tokens_in else ops.ncfhw_to_tokens(chunk.float().contiguous()[:, :, None], dt, cpad=8)
+                outs.append(self.vae.encode_tokens(tok))
+        lat = torch.cat(outs) * VAE_SCALE
+        return lat if index is None else lat[index]
 
     def _decode_frames(self, latents):
         """latents fp32 [1,4,F,h,w] -> video fp32 [1,3,F,H,W] in [0,1] (decode_latents, pipeline :113-126)."""
         dt = self.vae.compute_dtype
         _, C, F, h, w = latents.shape
-        z = ops.ncfhw_to_tokens((latents * (1.0 / VAE_SCALE)).contiguous(), dt, cpad=8)  # [F,h,w,8]
+        split = getattr(self.vae, "decode_precision", "half") == "split"
+        if split:
+            from .vae import nchw_to_tokens32
+            z = nchw_to_tokens32((latents[0] * (1.0 / VAE_SCALE)).permute(1, 0, 2, 3))  # fp32 [F,h,w,8]
+        else:
+            z = ops.ncfhw_to_tokens((latents * (1.0 / VAE_SCALE)).contiguous(), dt, cpad=8)  # [F,h,w,8]
         frames = []
-        nb = min(self.vae_batch, self.vae.max_images(8 * h, 8 * w))
+        nb = min(self.vae_batch, self.vae.max_images(8 * h, 8 * w, split=split))
         for i in range(0, F, nb):
-            y = self.vae.decode_tokens(z[i:i + nb].contiguous())
+            y = (self.vae.decode_tokens_split if split else self.vae.decode_tokens)(z[i:i + nb].contiguous())
             frames.append(ops.tokens_to_image(y, y.shape[0], y.shape[1], y.shape[2]))
         return torch.cat(frames).permute(1, 0, 2, 3)[None]
 

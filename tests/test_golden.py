@@ -154,20 +154,28 @@ def test_hip_vae_784_frame_vs_oracle_golden(full_models):
     e_dec = rel_l2(video, G["video_frame"])
     # the encoder sees the ORACLE's decoded image (video_frame = clamp(x / 2 + 0.5), the fixture encoded clamp(x, -1, 1)),
     # so its error is measured on identical inputs
+    assert vae.encode_precision == "split"  # the encoder's default policy (vae.py): hi + lo operand pairs
     enc = (vae.encode((G["video_frame"][None] * 2 - 1).to(dev)).latent_dist.mean.float() * 0.18215).cpu()
     e_enc = rel_l2(enc, G["reencoded_latent"])
+    vae.encode_precision = "half"
+    try:
+        e_enc_half = rel_l2((vae.encode((G["video_frame"][None] * 2 - 1).to(dev)).latent_dist.mean.float() * 0.18215).cpu(),
+                            G["reencoded_latent"])
+    finally:
+        vae.encode_precision = "split"
     vae.enable_tiling(96)  # 784 = 8 x 96 + 16: a ragged last band at the full-resolution levels
     try:
         tiled = vae.decode((G["latent"] / 0.18215).to(dev)).sample.float()
     finally:
         vae.disable_tiling()
     assert torch.equal(tiled, img), "tiled VAE decode must be bit-identical to the untiled one"
-    line = f"VAE 784x784 frame fp16 vs oracle fp32: decode rel_l2={e_dec:.2e}, encode(decoded) rel_l2={e_enc:.2e}; tiled decode (96-row bands) bit-identical"
+    line = (f"VAE 784x784 frame fp16 vs oracle fp32: decode rel_l2={e_dec:.2e}, encode(decoded) rel_l2={e_enc:.2e} (default policy 'split'; "
+            f"policy 'half': {e_enc_half:.2e}); tiled decode (96-row bands) bit-identical")
     print(line)
     _report(line)
     assert e_dec < 1e-3
-    north_star(_report, "VAE encode of one 784x784 frame (fp16, not a denoised-latents figure)", {"encode": e_enc}, 2e-3,
-               "fp16 weight rounding alone costs 1.27e-3 on the encoder (profiles/r4_error_budget_vae.txt): the policy's floor")
+    assert e_enc < 1e-3                # diffusers AutoencoderKL.encode as called at pipeline :427-439
+    assert e_enc_half < 1.4e-3         # the fast path (round 5: 1.18e-3): fp16 weight rounding alone costs 1.27e-3 in the oracle
 
 
 @pytest.mark.gpu

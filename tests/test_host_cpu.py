@@ -24,6 +24,40 @@ def test_library_exports_every_declared_symbol():
     assert cdll.mimo_version() >= 1
 
 
+def test_row_stat_slots_cover_only_whole_widest_tiles():
+    """the folded LayerNorm's producer epilogue has no column mask, so widths that are not a whole number
+    of the widest tile (480, 800, 960, 1920) and widths with more slots than a consumer row holds (2560) must report 0 slots —
+    ops.ln_foldable then falls back to out + layer_norm instead of corrupting the next row / raising.  Host-only entry point."""
+    from mimo_amd import lib
+    cdll = lib.load()
+    got = {N: cdll.mimo_row_stat_slots(N) for N in (320, 480, 640, 800, 960, 1280, 1920, 2560, 0, -64)}
+    assert got == {320: 4, 480: 0, 640: 8, 800: 0, 960: 0, 1280: 20, 1920: 0, 2560: 0, 0: 0, -64: 0}, got
+
+
+def test_split3_weight_packing():
+    """packing.pack_conv_split3 / pack_linear_split3: [Whi | Wlo | Whi] per tap, hi + lo reproduces the fp32 weight to 2^-21,
+    padding and the fused-shortcut segment land where ops.split3's [hi | hi | lo] channel blocks expect them."""
+    from mimo_amd.packing import pack_conv, pack_conv_split3, pack_linear_split3, split_hi_lo
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(12, 8, 3, 3, generator=g)
+    sc = torch.randn(12, 16, 1, 1, generator=g)
+    p3 = pack_conv_split3(w, torch.float16, shortcut=sc)
+    assert p3.shape == (12, 9 * 24 + 48) and p3.dtype == torch.float16
+    taps = p3[:, :9 * 24].reshape(12, 9, 3, 8).float()
+    assert torch.equal(taps[:, :, 0], taps[:, :, 2]) and torch.equal(taps[:, :, 0].reshape(12, -1), pack_conv(w, torch.float16).float())
+    ref = w.permute(0, 2, 3, 1).reshape(12, 9, 8)
+    assert float((taps[:, :, 0] + taps[:, :, 1] - ref).abs().max()) < 2 ** -20
+    s3 = p3[:, 9 * 24:].reshape(12, 3, 16).float()
+    assert float((s3[:, 0] + s3[:, 1] - sc.reshape(12, 16)).abs().max()) < 2 ** -20 and torch.equal(s3[:, 0], s3[:, 2])
+    thin = pack_conv_split3(torch.randn(4, 3, 3, 3, generator=g), torch.float16, cin_pad=8, k_pad=32, cout_pad=8)
+    assert thin.shape == (8, 9 * 32) and bool((thin.reshape(8, 9, 32)[:, :, 24:] == 0).all()) and bool((thin[4:] == 0).all())
+    assert bool((thin.reshape(8, 9, 32)[:, :, 3:8] == 0).all())
+    lin = pack_linear_split3(torch.randn(6, 8, generator=g), torch.bfloat16, rows_pad=8)
+    assert lin.shape == (8, 24) and torch.equal(lin[:, :8], lin[:, 16:])
+    hi, lo = split_hi_lo(torch.tensor([1.0 + 2 ** -12, 3.14159]), torch.float16)
+    assert float(hi[0]) == 1.0 and float(lo[0]) == 2 ** -12
+
+
 def test_build_compiles_every_hip_source():
     """Every .hip file under csrc/ is in build.SOURCES and every internal header in its dependency list: a kernel file that is
     not listed would silently be missing from libmimo_hip.so (and from the driver's build check)."""
@@ -920,4 +954,4 @@ def test_pack_ln_fold_is_the_layer_norm_followed_by_the_projection():
 
 def test_row_stat_slots_is_a_function_of_the_width_only():
     from mimo_amd import lib as L
-    assert [L.call_int("mimo_row_stat_slots", n) for n in (320, 640, 1280, 960, 100, 0)] == [4, 8, 20, 15, 0, 0]
+    assert [L.call_int("mimo_row_stat_slots", n) for n in (320, 640, 1280, 960, 100, 0)] == [4, 8, 20, 0, 0, 0]  # 960: not whole 256-wide tiles

@@ -198,22 +198,104 @@ def test_pose_guider(dev, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H,W", [(64, 64), (48, 80)])  # 48x80: 60 mid-block tokens, not a multiple of 8 (784^2 case)
 def test_vae_encode_decode(dev, dtype, H, W):
+    """Both precision policies of the VAE (vae.py): "split" (hi + lo operand pairs; the encoder's default) must meet the
+    north star's 1e-3 in isolation, "half" (plain 16-bit operands; the decoder's default) is reported under its guard."""
     ov, pv = build_pair_vae(dtype, dev)
+    assert (pv.encode_precision, pv.decode_precision) == ("split", "half")
     g = torch.Generator().manual_seed(5)
     img = torch.rand(2, 3, H, W, generator=g) * 2 - 1
-    ref_m = ov.encode(img).latent_dist.mean
-    out_m = pv.encode(img.to(dev)).latent_dist.mean.cpu()
     z = torch.randn(2, 4, H // 8, W // 8, generator=g)
+    ref_m = ov.encode(img).latent_dist.mean
     ref_d = ov.decode(z).sample
-    out_d = pv.decode(z.to(dev)).sample.cpu()
-    e1, e2 = rel_l2(out_m, ref_m), rel_l2(out_d, ref_d)
-    report(f"vae {dtype} {H}x{W}: encode rel_l2={e1:.2e} decode rel_l2={e2:.2e}")
-    # measured fp16 (round 4): encode 1.47e-3 / 1.55e-3, decode 2.14e-3 / 2.01e-3; bf16 scales with its 8x coarser mantissa
-    lim = {torch.float16: (2.0e-3, 2.9e-3), torch.bfloat16: (1.6e-2, 2.4e-2)}[dtype]
-    north_star(report, f"half-width VAE alone {H}x{W} {dtype} (not a denoised-latents figure)", {"encode": e1, "decode": e2},
-               {"encode": lim[0], "decode": lim[1]},
-               "16-bit MFMA operands: fp16 weight rounding alone is 1.3e-3 and the 3x3-conv operands 1.1e-3 on sd-vae-ft-mse "
-               "(profiles/r4_error_budget_vae.txt)" if dtype == torch.float16 else "bf16 operands: 8 mantissa bits (stated limit, DESIGN.md section 4)")
+    err = {}
+    for pol in ("split", "half"):
+        pv.encode_precision = pv.decode_precision = pol
+        err["encode", pol] = rel_l2(pv.encode(img.to(dev)).latent_dist.mean.cpu(), ref_m)
+        err["decode", pol] = rel_l2(pv.decode(z.to(dev)).sample.cpu(), ref_d)
+    pv.encode_precision, pv.decode_precision = "split", "half"
+    report(f"vae {dtype} {H}x{W}: split policy encode rel_l2={err['encode', 'split']:.2e} decode rel_l2={err['decode', 'split']:.2e} | "
+           f"half policy encode rel_l2={err['encode', 'half']:.2e} decode rel_l2={err['decode', 'half']:.2e}")
+    # split policy: ~22-bit operands whatever the 16-bit format — the bar holds for fp16 AND bf16
+    assert err["encode", "split"] < 1e-3 and err["decode", "split"] < 1e-3, err
+    # half policy, measured fp16 (round 5): encode 1.47e-3 / 1.55e-3, decode 2.14e-3 / 2.01e-3; bf16 scales with its mantissa.
+    # The decoder's DEFAULT is "half" (full-size sd-vae-ft-mse decode measures 4.2e-4 at 784x784, tests/test_golden.py);
+    # on these half-width random-weight models it misses the bar, which is reported as such.
+    lim = {torch.float16: (1.9e-3, 2.6e-3), torch.bfloat16: (1.6e-2, 2.1e-2)}[dtype]
+    assert err["encode", "half"] < lim[0], err
+    north_star(report, f"half-width VAE alone {H}x{W} {dtype}, DECODE under its default policy 'half' (not a denoised-latents figure; "
+               f"policy 'split' measures {err['decode', 'split']:.2e})", {"decode": err["decode", "half"]}, {"decode": lim[1]},
+               "16-bit MFMA operands: fp16 weight rounding alone is 1.4e-3 and the 3x3-conv operands 1.2e-3 on the decoder "
+               "(profiles/r4_error_budget_vae.txt); decode_precision = 'split' meets the bar at 3x the decoder's MFMA work"
+               if dtype == torch.float16 else "bf16 operands: 8 mantissa bits (stated limit, DESIGN.md section 4)")
+
+
+def test_split3_operands_carry_the_fp32_product(dev):
+    """ops.split3 + packing.pack_*_split3 through the ordinary GEMM / conv kernels against an fp64 product: ~1e-6, where plain
+    fp16 operands give ~3e-4; the GroupNorm + SiLU form against torch; the zero padding of ld > 3C."""
+    from mimo_amd import ops
+    from mimo_amd.packing import pack_conv, pack_conv_split3, pack_linear_split3
+    g = torch.Generator().manual_seed(9)
+    for dtype, tol in ((torch.float16, 3e-6), (torch.bfloat16, 6e-5)):
+        a = torch.randn(512, 64, generator=g).to(dev)
+        w = torch.randn(96, 64, generator=g).to(dev)
+        ref = a.double() @ w.double().t()
+        out = ops.gemm(ops.split3(a, dtype=dtype), pack_linear_split3(w, dtype), out_f32=True)
+        plain = ops.gemm(a.to(dtype), w.to(dtype).contiguous(), out_f32=True)
+        e3, e1 = rel_l2(out.cpu(), ref.cpu()), rel_l2(plain.cpu(), ref.cpu())
+        assert e3 < tol and e1 > 20 * e3, (dtype, e3, e1)
+        # 3x3 conv with GroupNorm + SiLU in front and a fused 1x1 shortcut segment
+        x = torch.randn(2, 16, 24, 32, generator=g).to(dev)               # [n, H, W, C]
+        cw = (torch.randn(48, 32, 3, 3, generator=g) * 0.1).to(dev)
+        sw = (torch.randn(48, 32, 1, 1, generator=g) * 0.1).to(dev)
+        gam, bet = torch.randn(32, generator=g).to(dev), torch.randn(32, generator=g).to(dev)
+        st = ops.group_norm_stats(x, groups=8, eps=1e-6, dtype=dtype)
+        a3 = ops.split3(x, st, gam, bet, groups=8, silu=True, dtype=dtype)
+        y = ops.conv2d(a3, pack_conv_split3(cw, dtype, shortcut=sw), 48, x2=ops.split3(x, dtype=dtype), out_f32=True)
+        xn = x.permute(0, 3, 1, 2).double()
+        rn = torch.nn.functional.silu(torch.nn.functional.group_norm(xn, 8, gam.double(), bet.double(), 1e-6))
+        rc = torch.nn.functional.conv2d(rn, cw.double(), padding=1) + torch.nn.functional.conv2d(xn, sw.double())
+        e = rel_l2(y.permute(0, 3, 1, 2).cpu(), rc.cpu())
+        assert e < 20 * tol, (dtype, e)   # (the device's fast exp in SiLU and the fp32 statistics are part of this figure)
+        pad = ops.split3(x[..., :8].contiguous(), dtype=dtype, ld=32)
+        assert pad.shape[-1] == 32 and bool((pad[..., 24:] == 0).all()) and torch.equal(pad[..., :8], pad[..., 8:16])
+        assert torch.equal(pad[..., :8], x[..., :8].to(dtype))
+
+
+def test_frames_differ_and_encoder_dedup(dev):
+    """mimo_frames_differ flags run starts; Pose2VideoPipeline._encode_frames encodes one frame per run of identical frames
+    and returns exactly what the frame-by-frame encode returns."""
+    from mimo_amd import ops
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    g = torch.Generator().manual_seed(12)
+    a, b = torch.rand(3, 32, 32, generator=g) * 2 - 1, torch.rand(3, 32, 32, generator=g) * 2 - 1
+    c = b.clone()
+    c[2, 31, 31] += 1e-6  # one element, last position
+    frames = torch.stack([a, a, a, b, b, c, a]).to(dev)
+    assert ops.frames_differ(frames).tolist() == [1, 0, 0, 1, 0, 1, 1]
+    assert ops.frames_differ(frames[:1].contiguous()).tolist() == [1]
+    assert ops.frames_differ(torch.zeros(4, 3, device=dev)) is None  # 12-byte frames: not comparable in 16-byte pieces
+    _, pv = build_pair_vae(torch.float16, dev)
+    pipe = Pose2VideoPipeline(pv, None, None, None, None, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    for pol in ("split", "half"):
+        pv.encode_precision = pol
+        pipe.vae_batch = 8
+        ops.COUNTER = {"flops": 0, "launches": 0}
+        lat = pipe._encode_frames(frames)
+        dedup_flops = ops.COUNTER["flops"]
+        pipe.dedup_frames = False
+        ops.COUNTER = {"flops": 0, "launches": 0}
+        with ops.split_k(False):
+            full = pipe._encode_frames(frames)
+            all_flops, ops.COUNTER = ops.COUNTER["flops"], None
+            pipe.dedup_frames = True
+            lat_bi = pipe._encode_frames(frames)
+        assert lat.shape == full.shape == (7, 4, 4, 4)
+        assert torch.equal(lat_bi, full), pol      # batch-invariant launches (split-K off): bit for bit
+        assert rel_l2(lat.cpu(), full.cpu()) < 1e-5, pol
+        assert torch.equal(lat[0], lat[1]) and torch.equal(lat[3], lat[4]) and not torch.equal(lat[4], lat[5])
+        assert abs(dedup_flops / all_flops - 4 / 7) < 1e-6  # 4 runs of 7 frames
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
