@@ -350,21 +350,30 @@ def forward_output(pipe, dev, dtype, size):
 
 
 def shard_plan(a, frames, world):
-    """--shard-windows: what every rank runs per denoising step (whole windows as b = 2 forwards, single CFG halves as b = 1
-    forwards), the plan's cost per rank in batched-window units and the speed-up it bounds (mimo_amd.pipeline.plan_items)."""
+    """--shard-windows: the schedule every rank derives for the clip.  cross_step (default; mimo_amd.pipeline.plan_cross_step):
+    slots of (window, step) forwards with one all_gather per slot and no per-step barrier; step_sync (rounds 2-5; plan_items):
+    per step, whole windows as b = 2 forwards + single CFG halves as b = 1 forwards.  Costs in batched-window units."""
     if not a.shard_windows:
         return {}
     from mimo_amd.context import get_context_scheduler
-    from mimo_amd.pipeline import plan_items, plan_load
-    nw = len(get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4))
+    from mimo_amd.pipeline import best_cross_step_plan, cross_step_cost, plan_items, plan_load
+    windows = get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4)
+    nw = len(windows)
     cfg = a.guidance > 1.0
     load, bound = plan_load(nw, cfg, world)
-    return {"shard_plan": {"windows": nw, "units": nw * (2 if cfg else 1),
-                           "per_rank_items": [[("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in r]
-                                              for r in plan_items(nw, cfg, world)],
-                           "per_rank_cost": [round(x, 2) for x in load], "speedup_bound": round(bound, 2),
-                           "collective": "slot-wise all_gather_into_tensor of fp32 [24, h, w, 4] unit predictions (RCCL), "
-                                         "exposed_gather_ms = HIP-event time of the final exchange wait per clip"}}
+    sync = {"per_rank_items": [[("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in r]
+                               for r in plan_items(nw, cfg, world)],
+            "per_rank_cost_per_step": [round(x, 2) for x in load], "busiest_rank_cost": round(max(load) * a.ddim_steps, 2),
+            "speedup_bound": round(bound, 2)}
+    slots = best_cross_step_plan(windows, a.ddim_steps, world, cfg)
+    cost = cross_step_cost(slots)
+    cross = {"slots": len(slots), "items_per_slot": sorted({len(sl) for sl in slots}),
+             "forwards_per_rank": [sum(1 for sl in slots for it in sl if it[0] == r) for r in range(world)],
+             "busiest_rank_cost": round(cost, 2), "speedup_bound": round(nw * a.ddim_steps * (1.0 if cfg else 0.61) / cost, 2),
+             "first_slots": [[f"r{r}:w{w}@t{t}" + ("" if len(hv) == 2 or not cfg else ("c" if hv[0] else "u")) for r, w, t, hv in sl] for sl in slots[:3]]}
+    return {"shard_plan": {"windows": nw, "units": nw * (2 if cfg else 1), "plan": a.shard_plan, "cross_step": cross, "step_sync": sync,
+                           "collective": "all_gather_into_tensor of fp32 [24, h, w, 4] unit predictions per slot (RCCL), "
+                                         "exposed_gather_ms = HIP-event time the launch stream waits for the gathers per clip"}}
 
 
 def emulate_world(a, dev, dtype):
@@ -376,16 +385,23 @@ def emulate_world(a, dev, dtype):
     The busiest rank's time bounds the W-GPU step: speed-up <= single / max_k, before box-to-box spread and link time."""
     import torch.distributed as dist
     from mimo_amd.context import get_context_scheduler
-    from mimo_amd.pipeline import plan_items
+    from mimo_amd.pipeline import best_cross_step_plan, plan_items
     W = a.emulate_world
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29677", rank=0, world_size=1, device_id=dev)
     pipe = build_pipeline(dev, dtype)
+    pipe.shard_plan = a.shard_plan
     frames = a.frames * W
     inp = synthetic_inputs(dev, frames, a.size, seed=42)
     cfg = a.guidance > 1.0
-    nw = len(get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4))
-    items = plan_items(nw, cfg, W)
+    windows = get_context_scheduler("uniform")(0, a.ddim_steps, frames, 24, 1, 4)
+    nw = len(windows)
+    if a.shard_plan == "cross_step":
+        slots = best_cross_step_plan(windows, a.ddim_steps, W, cfg)
+        items = [[f"{sum(1 for sl in slots for it in sl if it[0] == k and len(it[3]) == 2)} windows (b = 2) + "
+                  f"{sum(1 for sl in slots for it in sl if it[0] == k and len(it[3]) == 1)} halves in {len(slots)} slots"] for k in range(W)]
+    else:
+        items = [[("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in r] for r in plan_items(nw, cfg, W)]
 
     def clip():
         emb = pipe.image_encoder(inp["clip_pixels"].to(dtype)).image_embeds
@@ -410,7 +426,7 @@ def emulate_world(a, dev, dtype):
         clip()
         st, pipe.stage_times = pipe.stage_times, None
         ms = timed(1)
-        per_rank.append({"rank": k, "items": [("window" if len(it) == 2 else ("cond" if it[0][1] else "uncond")) + str(it[0][0]) for it in items[k]],
+        per_rank.append({"rank": k, "items": items[k],
                          "ms_per_clip": round(ms, 1), "stage_ms": {n: round(v, 1) for n, v in st.items()}})
     pipe.shard_windows, pipe.shard_emulate = False, None
     clip()
@@ -419,7 +435,7 @@ def emulate_world(a, dev, dtype):
     clip()
     single_bi = timed(1)
     worst = max(r["ms_per_clip"] for r in per_rank)
-    print(json.dumps({"emulate_world": W, "frames": frames, "windows": nw, "size": a.size, "ddim_steps": a.ddim_steps, "dtype": a.dtype,
+    print(json.dumps({"emulate_world": W, "shard_plan": a.shard_plan, "frames": frames, "windows": nw, "size": a.size, "ddim_steps": a.ddim_steps, "dtype": a.dtype,
                       "per_rank": per_rank, "busiest_rank_ms": worst, "single_gpu_ms": round(single, 1),
                       "single_gpu_split_k_off_ms": round(single_bi, 1),
                       "speedup_bound_vs_single": round(single / worst, 2), "speedup_bound_vs_single_split_k_off": round(single_bi / worst, 2),
@@ -442,6 +458,9 @@ def main():
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--edit", action="store_true", help="add the `edit` sub-record: BASELINE configs[2], the whole run_edit.py path timed")
     ap.add_argument("--shard-windows", action="store_true")
+    ap.add_argument("--shard-plan", default="cross_step", choices=["cross_step", "step_sync"],
+                    help="schedule of the sharded long clip: slots of (window, step) forwards without a per-step barrier (default) | "
+                         "the per-step plan of rounds 2-5")
     ap.add_argument("--force-shard", action="store_true",
                     help="with --shard-windows under torchrun at world size 1: take the sharded (RCCL) code path anyway")
     ap.add_argument("--graphs", action="store_true", help="replay the denoising forward as a captured hipGraph "
@@ -488,6 +507,7 @@ def main():
     frames = a.frames * (world if a.shard_windows else 1)
     pipe.shard_windows = a.shard_windows and (world > 1 or (a.force_shard and use_dist))
     pipe.shard_force = bool(a.force_shard)
+    pipe.shard_plan = a.shard_plan
     pipe.use_graphs = a.graphs and not pipe.shard_windows
     if a.window_streams is not None:
         pipe.window_streams = a.window_streams

@@ -156,6 +156,161 @@ def plan_units(num_windows, cfg, rank, world):
     return units, [u for u, r, _ in assign_units(units, world, cfg) if r == rank]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Cross-step schedule of the sharded long clip (round 6).  Window w at step t + 1 needs the step-t predictions of the windows
+# that share a frame with it — w itself and its ring neighbours (4-frame overlaps, src/pipelines/context.py:15-42) — and of
+# nothing else: the reference's per-step loop (pipeline_pose2vid_long_edit_bkfill_roiclip.py:505-553) has no global barrier in
+# its arithmetic.  The (window, step) forwards are therefore laid into SLOTS of at most `world` items by a static list schedule;
+# every slot ends with ONE async all_gather of the ranks' predictions, after which every rank advances (window sum in canonical
+# order -> guidance -> DDIM, the single-GPU arithmetic per element) exactly the frames all of whose covering windows have
+# delivered.  BASELINE configs[3] (10 windows x 20 steps on 8 ranks): 200 whole-window (b = 2) forwards in 25 full slots —
+# every rank runs 25 forwards — where the step-synchronous plan (plan_items) keeps four ranks busy for 1.61 window-forwards
+# per step and idles the others: 32.2 against 25.0 window-forwards on the busiest rank.
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def window_neighbours(windows):
+    """nb[w] = the windows (w included) that share at least one frame with window w, ascending."""
+    sets = [set(c) for c in windows]
+    return [[v for v in range(len(windows)) if sets[w] & sets[v]] for w in range(len(windows))]
+
+
+def interleaved_order(n):
+    """0, n-1, 1, n-2, ...: on a ring of n windows every window's neighbours sit within two positions of it, so the items
+    of step t + 1 become ready in the order those of step t are issued."""
+    out, lo, hi = [], 0, n - 1
+    while lo <= hi:
+        out.append(lo)
+        if hi != lo:
+            out.append(hi)
+        lo, hi = lo + 1, hi - 1
+    return out
+
+
+def plan_cross_step(windows, steps, world, cfg=True, order=None):
+    """Static schedule of the (window, step) forwards: a list of slots, each a list of (rank, w, t, halves) with halves = (0, 1)
+    for a whole window (one b = 2 forward when cfg, else (0,)) or (h,) for one CFG half (a b = 1 forward).  An item enters a
+    slot only if every step-(t - 1) item of its neighbour windows sits in an EARLIER slot (their predictions are gathered at
+    the end of that slot).  Greedy by (step, position in `order`); a slot whose ready windows fill at most half the ranks runs
+    them as CFG halves on two ranks each (a half costs 0.69 of a batched window).  Deterministic: every rank computes the
+    same plan."""
+    nw = len(windows)
+    nb = window_neighbours(windows)
+    pos = {w: i for i, w in enumerate(order if order is not None else interleaved_order(nw))}
+    pending = sorted(((t, pos[w], w) for t in range(steps) for w in range(nw)))
+    done = {}
+    slots = []
+    while pending:
+        s = len(slots)
+        ready = []
+        for it in pending:
+            t, _, w = it
+            if t == 0 or all(done.get((v, t - 1), s) < s for v in nb[w]):
+                ready.append(it)
+                if len(ready) == world:
+                    break
+        assert ready, "dependency cycle in the window schedule"
+        slot = []
+        if cfg and 2 * len(ready) <= world:
+            for j, (t, _, w) in enumerate(ready):
+                slot += [(2 * j, w, t, (1,)), (2 * j + 1, w, t, (0,))]   # the cond half (it attends the bank too) first
+        else:
+            for j, (t, _, w) in enumerate(ready):
+                slot.append((j, w, t, (0, 1) if cfg else (0,)))
+        for t, _, w in ready:
+            done[(w, t)] = s
+        taken = set(ready)
+        pending = [it for it in pending if it not in taken]
+        slots.append(slot)
+    return slots
+
+
+def cross_step_cost(slots):
+    """Busiest-rank cost of a plan in batched-window units: every slot lasts as long as its most expensive item."""
+    def c(halves):
+        return ITEM_COST["window"] if len(halves) == 2 else ITEM_COST["cond"] if halves[0] == 1 else ITEM_COST["uncond"]
+    return sum(max(c(h) for _, _, _, h in slot) for slot in slots)
+
+
+def best_cross_step_plan(windows, steps, world, cfg=True):
+    """The cheaper of the interleaved and the natural window order (cross_step_cost; ties to the interleaved one)."""
+    a = plan_cross_step(windows, steps, world, cfg)
+    b = plan_cross_step(windows, steps, world, cfg, order=list(range(len(windows))))
+    return a if cross_step_cost(a) <= cross_step_cost(b) + 1e-9 else b
+
+
+def frame_segments(windows, num_frames):
+    """[(cover, frames)]: the frames grouped by the set of windows that contain them (cover = ascending window tuple), in
+    order of first frame.  A segment advances from step t to t + 1 when every window of its cover has delivered step t."""
+    cover = [[] for _ in range(num_frames)]
+    for w, c in enumerate(windows):
+        for f in c:
+            cover[f].append(w)
+    segs = {}
+    for f in range(num_frames):
+        segs.setdefault(tuple(cover[f]), []).append(f)
+    return sorted(segs.items(), key=lambda kv: kv[1][0])
+
+
+def cross_step_lifetime(slots, windows, num_frames):
+    """How many slots a gathered prediction must stay readable: max over items of (slot in which the last segment it feeds
+    becomes ready) - (its own slot) + 1."""
+    done = {(w, t): s for s, slot in enumerate(slots) for _, w, t, _ in slot}
+    life = 1
+    for cover, _ in frame_segments(windows, num_frames):
+        for t in {t for _, t in done}:
+            last = max(done[(w, t)] for w in cover)
+            life = max(life, 1 + max(last - done[(w, t)] for w in cover))
+    return life
+
+
+class SlotExchange:
+    """Per-slot exchange of the cross-step schedule: every rank contributes up to two unit predictions (fp32 [Fw, h, w, C]:
+    uncond + cond of a whole window, or one CFG half) per slot; slot s of all ranks is all-gathered asynchronously (RCCL's own
+    stream, ordered behind the producing kernels) into buffer s % depth, `depth` = how long a prediction stays needed."""
+
+    def __init__(self, rank, world, shape, depth, device, group=None):
+        self.rank, self.world, self.group, self.depth = rank, world, group, depth
+        self.send = torch.zeros((depth, 2) + tuple(shape), device=device, dtype=torch.float32)
+        self.recv = torch.zeros((depth, world, 2) + tuple(shape), device=device, dtype=torch.float32)
+        self.work = {}
+        self.emulated = False
+
+    def start(self, s, preds):
+        import torch.distributed as dist
+        d = s % self.depth
+        for k, p in enumerate(preds):
+            self.send[d, k].copy_(p)
+        if dist.get_world_size(self.group) != self.world:
+            # one rank of a larger world emulated on a single GPU (Pose2VideoPipeline.shard_emulate): the collective runs on the
+            # real group with 1 / world of the bytes; the other ranks' entries are stand-ins
+            self.emulated = True
+            self.work[s] = dist.all_gather_into_tensor(self.recv[d, 0].view(-1), self.send[d].view(-1), group=self.group, async_op=True)
+        elif self.send.is_cuda and dist.get_backend(self.group) == "gloo":  # no device collectives in gloo: host staging
+            host = self.send[d].reshape(-1).cpu()
+            out = torch.empty((self.world * host.numel(),), dtype=host.dtype)
+            dist.all_gather_into_tensor(out, host, group=self.group)
+            self.recv[d].copy_(out.view(self.recv[d].shape))
+        else:
+            self.work[s] = dist.all_gather_into_tensor(self.recv[d].view(-1), self.send[d].view(-1), group=self.group, async_op=True)
+
+    def wait(self, s):
+        w = self.work.pop(s, None)
+        if w is not None:
+            w.wait()
+        if self.emulated:
+            d = s % self.depth
+            self.recv[d, 1:] = self.recv[d, :1]
+
+    def unit(self, s, rank, k):
+        return self.recv[s % self.depth, rank, k]
+
+    def pair(self, s, rank):
+        """both units of a whole-window item as one [2 Fw, h, w, C] prediction (uncond rows first)."""
+        r = self.recv[s % self.depth, rank]
+        return r.view((r.shape[0] * r.shape[1],) + tuple(r.shape[2:]))
+
+
 def _all_gather(send, world, group=None):
     """all_gather of equal-shape tensors.  RCCL (backend "nccl") takes device tensors as they are; the gloo backend
     (CPU tests, and the 2-ranks-on-one-GPU test) has no device all_gather, so device tensors are staged through the host."""
@@ -343,6 +498,8 @@ class Pose2VideoPipeline:
         self.shard_force = False    # True: take the sharded code path (unit plan, per-slot async all_gather on the backend's
         #                             stream, item streams, sharded per-frame stages) even in a group of ONE rank — how the RCCL
         #                             branch is exercised on a single-GPU box (tests/test_models_gpu.py, bench.py --force-shard)
+        self.shard_plan = "cross_step"  # how the sharded clip's forwards are scheduled: "cross_step" (plan_cross_step: slots of
+        #                             (window, step) items, no per-step barrier) | "step_sync" (plan_items: the round 2-5 per-step plan)
         self.batch_invariant = False  # True: bit-identical to the sharded run of the same clip (split-K off)
         self.use_graphs = False     # True: replay the denoising forward as a captured hipGraph (single-GPU path)
         self.window_streams = 2     # > 1: the independent windows of one step run on this many HIP streams (single-GPU path)
@@ -571,7 +728,7 @@ class Pose2VideoPipeline:
         # instead of four M = 2 launches per forward (they depend on (t, clip embedding) only)
         temb_tab, attn2_tab = unet.clip_tables(steps_t, ehs, 2 if cfg else 1)
         units, my_units = plan_units(len(windows), cfg, rank, world)
-        my_items = plan_items(len(windows), cfg, world)[rank] if sharded else []
+        my_items = plan_items(len(windows), cfg, world)[rank] if (sharded and self.shard_plan != "cross_step") else []
         item_x, item_pose = [], []
         for item in my_items:  # per-item UNet input / pose buffers of the sharded mode (same layout as win_x)
             c = win_idx[item[0][0]]
@@ -581,14 +738,18 @@ class Pose2VideoPipeline:
             item_pose.append(pose_tok[c.long()].repeat(len(item), 1, 1, 1))
         counter_x = torch.zeros((F,), device=dev, dtype=torch.float32)  # the cond half's (unused) frame counter
         exch = None
-        if sharded:  # every window has the same frame count; the UNet's output head is padded to 4 channels
+        if sharded and self.shard_plan != "cross_step":  # every window has the same frame count; the UNet's output head is padded to 4 channels
             cpad = (unet.out_channels + 3) // 4 * 4
             exch = UnitExchange(units, rank, world, (len(windows[0]), h, w, cpad), dev, self.dist_group)
         gather_marks = []
         acc = torch.empty((2 if cfg else 1, C, F, h, w), device=dev, dtype=torch.float32)
         counter = torch.empty((F,), device=dev, dtype=torch.float32)
 
-        for step, t in enumerate(steps_t):
+        cross = sharded and self.shard_plan == "cross_step"
+        if cross:
+            gather_marks = self._denoise_cross_step(latents, windows, win_idx, bk_tok, pose_tok, temb_tab, attn2_tab, ehs, steps_t,
+                                                    cfg, guidance_scale, rank, world, callback, trajectory)
+        for step, t in enumerate(() if cross else steps_t):
             tk = dict(temb=temb_tab[step], attn2=attn2_tab)
             acc.zero_()
             counter.zero_()
@@ -701,6 +862,126 @@ class Pose2VideoPipeline:
                 self.stage_times["exposed_gather_ms"] = self.stage_times.get("exposed_gather_ms", 0.0) + \
                     sum(g0.elapsed_time(g1) for g0, g1 in gather_marks)
         return (video, latents) if return_latents else video
+
+    def _denoise_cross_step(self, latents, windows, win_idx, bk_tok, pose_tok, temb_tab, attn2_tab, ehs, steps_t, cfg,
+                            guidance_scale, rank, world, callback, trajectory):
+        """The denoising loop of the sharded long clip under the cross-step schedule (plan_cross_step): this rank runs its
+        item of every slot, hands the prediction(s) to the slot's all_gather, and — like every other rank — advances the frames
+        whose covering windows have all delivered.  Per element the arithmetic is the single-GPU loop's (canonical window
+        order, mimo_cfg_ddim_step), so the clip reproduces the single-GPU bits."""
+        dev = self.device
+        unet, sched = self.denoising_unet, self.scheduler
+        dt = unet.compute_dtype
+        _, C, F, h, w = latents.shape
+        T = len(steps_t)
+        slots = best_cross_step_plan(windows, T, world, cfg)
+        segs = frame_segments(windows, F)
+        depth = cross_step_lifetime(slots, windows, F) + 1   # + 1: slot s + 1 is being written while slot s is still read
+        Fw = len(windows[0])
+        cpad = (unet.out_channels + 3) // 4 * 4
+        exch = SlotExchange(rank, world, (Fw, h, w, cpad), depth, dev, self.dist_group)
+        nb = 2 if cfg else 1
+        acc = torch.empty((nb, C, F, h, w), device=dev, dtype=torch.float32)
+        counter = torch.empty((F,), device=dev, dtype=torch.float32)
+        counter_x = torch.zeros((F,), device=dev, dtype=torch.float32)  # the cond half's (unused) frame counter
+        frame_step = [0] * F              # host mirror: the step each frame's latent is at
+        where = {}                        # (w, t) -> [(slot, rank, halves)]: where the gathered prediction(s) sit
+        in_x, in_pose = {}, {}            # per (window, rows) input buffers of this rank (background half written once)
+        idx_cache = {}
+        snaps = {} if (trajectory is not None or callback is not None) else None
+        reported = 0
+        gather_marks = []
+
+        def dev_idx(key, values):
+            t_ = idx_cache.get(key)
+            if t_ is None:
+                t_ = idx_cache[key] = torch.tensor(values, dtype=torch.int32, device=dev)
+            return t_
+
+        def item_input(wi, rows):
+            key = (wi, rows)
+            if key not in in_x:
+                c = win_idx[wi].long()
+                xw = torch.empty((rows * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+                xw[..., C:] = bk_tok[c].repeat(rows, 1, 1, 1)
+                in_x[key], in_pose[key] = xw, pose_tok[c].repeat(rows, 1, 1, 1)
+            return in_x[key], in_pose[key]
+
+        def advance(s):
+            """after slot s's gather: advance every frame segment that has become complete, lowest step first."""
+            nonlocal reported
+            for t in sorted({frame_step[fr[0]] for _, fr in segs}):
+                if t >= T:
+                    continue
+                ready = [(cv, fr) for cv, fr in segs if frame_step[fr[0]] == t and all((v, t) in where for v in cv)]
+                if not ready:
+                    continue
+                group = sorted(f for _, fr in ready for f in fr)
+                gset = set(group)
+                acc.zero_()
+                counter.zero_()
+                for wi in sorted({v for cv, _ in ready for v in cv}):       # canonical window order
+                    mask = dev_idx(("m", wi, tuple(group)), [f if f in gset else -1 for f in windows[wi]])
+                    for (s0, r0, halves) in where[(wi, t)]:
+                        if len(halves) == 2:
+                            ops.window_accumulate(exch.pair(s0, r0), mask, acc, counter)
+                        elif not cfg:
+                            ops.window_accumulate(exch.unit(s0, r0, 0), mask, acc, counter)
+                        else:
+                            hf = halves[0]
+                            ops.window_accumulate(exch.unit(s0, r0, 0), mask, acc[hf:hf + 1], counter if hf == 0 else counter_x)
+                gi = dev_idx(("g", tuple(group)), group)
+                ops.cfg_ddim_step(acc, counter, latents, cfg, guidance_scale, *sched.coefficients(steps_t[t]), frames=gi)
+                for f in group:
+                    frame_step[f] = t + 1
+                if snaps is not None:
+                    if t not in snaps:
+                        snaps[t] = torch.empty_like(latents)
+                    snaps[t][:, :, gi.long()] = latents[:, :, gi.long()]
+            while snaps is not None and reported < T and min(frame_step) > reported:
+                snap = snaps.pop(reported)
+                if trajectory is not None:
+                    trajectory.append(snap)
+                if callback is not None:
+                    callback(reported, steps_t[reported], snap)
+                reported += 1
+
+        for s, slot in enumerate(slots):
+            mine = [it for it in slot if it[0] == rank]
+            preds = []
+            for _, wi, t, halves in mine:
+                idx, n_f = win_idx[wi], win_idx[wi].numel()
+                assert all(frame_step[f] == t for f in windows[wi]), "cross-step plan ran ahead of its dependencies"
+                x, pose = item_input(wi, len(halves))
+                for r_ in range(len(halves)):
+                    ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=x[r_ * n_f:(r_ + 1) * n_f])
+                if len(halves) == 2:
+                    pred = unet.run_tokens(x, steps_t[t], ehs, 2, n_f, pose, temb=temb_tab[t], attn2=attn2_tab)
+                    preds = [pred[:n_f], pred[n_f:]]
+                else:
+                    hf = halves[0]
+                    e = ehs[hf:hf + 1] if cfg else ehs
+                    preds = [self._run_unit(unet, x, steps_t[t], e, n_f, pose, cond=(hf == 1 or not cfg),
+                                            temb=temb_tab[t][hf:hf + 1], attn2=attn2_tab[hf:hf + 1])]
+            exch.start(s, preds)
+            if self.stage_times is not None:
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record()
+            exch.wait(s)
+            if self.stage_times is not None:
+                g1 = torch.cuda.Event(enable_timing=True)
+                g1.record()
+                gather_marks.append((g0, g1))
+            for r0, wi, t, halves in slot:
+                where.setdefault((wi, t), []).append((s, r0, halves))
+            advance(s)
+            for key in [k for k, v in where.items() if all(s - s0 >= depth - 2 for s0, _, _ in v)]:
+                # (ring entries two slots from being overwritten must have been consumed: every frame of the window is past t)
+                assert all(frame_step[f] > key[1] for f in windows[key[0]]), "gather ring too shallow"
+                del where[key]
+        assert min(frame_step) == T and max(frame_step) == T
+        return gather_marks
+
 
     def _run_unit(self, unet, x, t, ehs1, Fw, pose, cond, **tables):
         """One (window, CFG half) unit as a b = 1 forward.  The uncond half must not read the bank."""

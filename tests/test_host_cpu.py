@@ -281,6 +281,177 @@ def test_exchange_predictions_gloo(world, nw):
     assert all(ok for _, ok, _ in res) and len({t for _, _, t in res}) == 1
 
 
+def test_cross_step_plan_properties():
+    """plan_cross_step (round 6): every (window, step) forward exactly once (as one b = 2 item or as its two CFG halves), at
+    most one item per rank and slot, every item strictly after the step-(t - 1) items of the windows it shares frames with;
+    BASELINE configs[3] (192 frames = 10 ring windows, 20 steps, 8 ranks) packs into 25 FULL slots — 25 forwards per rank
+    against 32.2 window-forward units on the busiest rank of the per-step plan."""
+    from mimo_amd.context import uniform
+    from mimo_amd.pipeline import (best_cross_step_plan, cross_step_cost, cross_step_lifetime, frame_segments, interleaved_order,
+                                   plan_load, window_neighbours)
+    assert interleaved_order(10) == [0, 9, 1, 8, 2, 7, 3, 6, 4, 5] and interleaved_order(3) == [0, 2, 1] and interleaved_order(1) == [0]
+    for F, world, steps, cfg in ((192, 8, 20, True), (192, 4, 20, True), (192, 16, 20, True), (48, 2, 4, True), (24, 2, 3, True),
+                                 (26, 2, 2, True), (50, 2, 2, True), (50, 4, 5, False), (192, 3, 7, True), (100, 8, 6, True), (24, 1, 2, True)):
+        windows = uniform(0, steps, F, 24, 1, 4)
+        nb = window_neighbours(windows)
+        slots = best_cross_step_plan(windows, steps, world, cfg)
+        at, halves_seen = {}, {}
+        for s_, slot in enumerate(slots):
+            ranks = [r for r, _, _, _ in slot]
+            assert len(set(ranks)) == len(ranks) and all(0 <= r < world for r in ranks)
+            for r, w, t, hv in slot:
+                assert hv in (((0, 1), (0,), (1,)) if cfg else ((0,),))
+                halves_seen.setdefault((w, t), []).extend(hv)
+                assert at.setdefault((w, t), s_) == s_          # the two halves of a split window share a slot
+        want = [0, 1] if cfg else [0]
+        assert set(at) == {(w, t) for w in range(len(windows)) for t in range(steps)}
+        assert all(sorted(v) == want for v in halves_seen.values())
+        for (w, t), s_ in at.items():
+            assert t == 0 or all(at[(v, t - 1)] < s_ for v in nb[w]), (F, world, w, t)
+        assert cross_step_cost(slots) <= max(plan_load(len(windows), cfg, world)[0]) * steps + 1e-9, (F, world)
+        segs = frame_segments(windows, F)
+        assert sorted(f for _, fr in segs for f in fr) == list(range(F))
+        assert 1 <= cross_step_lifetime(slots, windows, F) <= len(slots)
+    windows = uniform(0, 20, 192, 24, 1, 4)
+    slots = best_cross_step_plan(windows, 20, 8, True)
+    assert len(slots) == 25 and all(len(sl) == 8 and all(len(hv) == 2 for _, _, _, hv in sl) for sl in slots)
+    assert cross_step_cost(slots) == 25.0 and abs(max(plan_load(10, True, 8)[0]) * 20 - 32.2) < 1e-6
+    assert cross_step_lifetime(slots, windows, 192) == 2
+
+
+class _FakeUNet:
+    """Stand-in for the denoising UNet in the CPU test of the cross-step executor: a deterministic elementwise function of the
+    window's latents, the step and the CFG half (the cond row's hidden state is non-zero)."""
+    compute_dtype = torch.float32
+    out_channels = 4
+    device = torch.device("cpu")
+
+    def spatial_blocks(self):
+        return []
+
+    def run_tokens(self, x, t, ehs, b, F, pose, temb=None, attn2=None):
+        lat = x[..., :4].float()
+        mark = ehs.reshape(b, -1).sum(1).repeat_interleave(F)[:, None, None, None]
+        return torch.sin(lat * 1.3 + 0.01 * float(t) + mark) + 0.25 * lat + pose[..., :4]
+
+
+def _cpu_ops_patch():
+    """torch stand-ins for the three elementwise C-ABI entry points the loop calls (same per-element arithmetic and order)."""
+    from mimo_amd import ops
+
+    def ncfhw_to_tokens(x, dtype, frame_idx=None, cpad=None, out=None, out_col0=0):
+        out[..., :x.shape[1]] = x[0][:, frame_idx.long()].permute(1, 2, 3, 0).to(out.dtype)
+        return out
+
+    def window_accumulate(pred, frames, acc, counter):
+        bb, Fw = acc.shape[0], frames.numel()
+        for bi in range(bb):
+            for j, f in enumerate(frames.tolist()):
+                if f >= 0:
+                    acc[bi, :, f] += pred[bi * Fw + j, :, :, :acc.shape[1]].permute(2, 0, 1)
+        for f in frames.tolist():
+            if f >= 0:
+                counter[f] += 1.0
+
+    def cfg_ddim_step(acc, counter, lat, cfg, g, sa, s1, sap, s1p, frames=None):
+        fr = list(range(lat.shape[2])) if frames is None else frames.tolist()
+        for f in fr:
+            if cfg:
+                un, co = acc[0, :, f] / counter[f], acc[1, :, f] / counter[f]
+                np_ = un + g * (co - un)
+            else:
+                np_ = acc[0, :, f]
+            x = lat[0, :, f]
+            lat[0, :, f] = sap * (sa * x - s1 * np_) + s1p * (sa * np_ + s1 * x)
+
+    ops.ncfhw_to_tokens, ops.window_accumulate, ops.cfg_ddim_step = ncfhw_to_tokens, window_accumulate, cfg_ddim_step
+
+
+def _cross_step_case(F, steps, cfg):
+    from mimo_amd.context import uniform
+    g = torch.Generator().manual_seed(F * 31 + steps)
+    windows = uniform(0, steps, F, 24, 1, 4)
+    lat = torch.randn(1, 4, F, 3, 2, generator=g)
+    bk = torch.randn(F, 3, 2, 4, generator=g)
+    pose = torch.randn(F, 3, 2, 4, generator=g) * 0.1
+    e = torch.randn(1, 1, 8, generator=g)
+    ehs = torch.cat([torch.zeros_like(e), e]) if cfg else e
+    return windows, lat, bk, pose, ehs
+
+
+def _cross_step_worker(rank, world, port, q, F, steps, cfg):
+    import torch.distributed as dist
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        _cpu_ops_patch()
+        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg)
+        pipe = Pose2VideoPipeline.__new__(Pose2VideoPipeline)
+        pipe.denoising_unet, pipe.scheduler = _FakeUNet(), DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
+        pipe.dist_group, pipe.stage_times = None, None
+        pipe.scheduler.set_timesteps(steps)
+        steps_t = pipe.scheduler.timesteps.tolist()
+        win_idx = [torch.tensor(c, dtype=torch.int32) for c in windows]
+        traj, seen = [], []
+        pipe._denoise_cross_step(lat, windows, win_idx, bk, pose, [None] * steps if False else [torch.zeros(2 if cfg else 1, 1)] * steps,
+                                 torch.zeros(2 if cfg else 1, 1), ehs, steps_t, cfg, 3.5, rank, world,
+                                 lambda i, t, l: seen.append((i, t)), traj)
+        q.put((rank, lat.numpy(), [x.numpy() for x in traj], seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,steps,cfg", [(8, 192, 6, True), (4, 100, 4, True), (2, 50, 3, True), (2, 24, 3, True), (3, 72, 3, False)])
+def test_cross_step_executor_gloo_equals_sequential_loop(world, F, steps, cfg):
+    """Pose2VideoPipeline._denoise_cross_step over gloo (world 8: the 10-window clip of BASELINE configs[3]) with a stand-in
+    UNet and torch stand-ins for the elementwise kernels: every rank ends with the latents — and the per-step trajectory, and
+    the callback order — of the plain per-step loop (all windows, canonical-order sum, guidance, DDIM), bit for bit.  Covers
+    the slot dependency order, the gather ring's depth, the frame-segment updates, split windows (F = 24 on 2 ranks) and the
+    no-CFG form."""
+    import torch.multiprocessing as mp
+    from mimo_amd import ops
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    saved = (ops.ncfhw_to_tokens, ops.window_accumulate, ops.cfg_ddim_step)
+    try:
+        _cpu_ops_patch()
+        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg)
+        sched = DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
+        sched.set_timesteps(steps)
+        net, ref_traj = _FakeUNet(), []
+        nb = 2 if cfg else 1
+        for t in sched.timesteps.tolist():
+            acc, counter = torch.zeros(nb, 4, F, 3, 2), torch.zeros(F)
+            for c in windows:
+                idx = torch.tensor(c, dtype=torch.int32)
+                x = torch.empty(nb * len(c), 3, 2, 8)
+                for r_ in range(nb):
+                    ops.ncfhw_to_tokens(lat, torch.float32, frame_idx=idx, cpad=4, out=x[r_ * len(c):(r_ + 1) * len(c)])
+                x[..., 4:] = bk[idx.long()].repeat(nb, 1, 1, 1)
+                ops.window_accumulate(net.run_tokens(x, t, ehs, nb, len(c), pose[idx.long()].repeat(nb, 1, 1, 1)), idx, acc, counter)
+            ops.cfg_ddim_step(acc, counter, lat, cfg, 3.5, *sched.coefficients(t))
+            ref_traj.append(lat.clone())
+    finally:
+        ops.ncfhw_to_tokens, ops.window_accumulate, ops.cfg_ddim_step = saved
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29200 + (os.getpid() * 3 + world * 17 + F) % 700
+    procs = [ctx.Process(target=_cross_step_worker, args=(r, world, port, q, F, steps, cfg)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p_ in procs:
+        p_.join(60)
+    want_seen = [(i, t) for i, t in enumerate(sched.timesteps.tolist())]
+    for rank, out, traj, seen in res:
+        assert torch.equal(torch.from_numpy(out), lat), rank
+        assert len(traj) == steps and all(torch.equal(torch.from_numpy(a), b) for a, b in zip(traj, ref_traj)), rank
+        assert seen == want_seen, rank
+
+
+
 def test_clip_image_encoder_state_dict_matches_transformers():
     """mimo_amd.clip mirrors transformers.CLIPVisionModelWithProjection key for key (ViT-L/14 shapes on the meta device)."""
     from transformers import CLIPVisionConfig

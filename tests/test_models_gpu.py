@@ -271,7 +271,7 @@ def test_frames_differ_and_encoder_dedup(dev):
     g = torch.Generator().manual_seed(12)
     a, b = torch.rand(3, 32, 32, generator=g) * 2 - 1, torch.rand(3, 32, 32, generator=g) * 2 - 1
     c = b.clone()
-    c[2, 31, 31] += 1e-6  # one element, last position
+    c[2, 31, 31] += 0.25  # one element, the last position of the frame
     frames = torch.stack([a, a, a, b, b, c, a]).to(dev)
     assert ops.frames_differ(frames).tolist() == [1, 0, 0, 1, 0, 1, 1]
     assert ops.frames_differ(frames[:1].contiguous()).tolist() == [1]
@@ -504,16 +504,16 @@ def test_clip_image_encoder_vs_transformers(dev, dtype, size):
     assert e1 < 3 * TOL[dtype] and e2 < 3 * TOL[dtype]
 
 
-def _sharded_clip_worker(rank, world, port, q, F=26):
+def _sharded_clip_worker(rank, world, port, q, F=26, plan="cross_step"):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        q.put((rank, _small_clip(torch.device("cuda:0"), shard=True, F=F).cpu().numpy()))  # by value: the worker exits
+        q.put((rank, _small_clip(torch.device("cuda:0"), shard=True, F=F, plan=plan).cpu().numpy()))  # by value: the worker exits
     finally:
         dist.destroy_process_group()
 
 
-def _rccl_world1_worker(port, q, F):
+def _rccl_world1_worker(port, q, F, plan="cross_step"):
     """One rank, backend "nccl" (= RCCL): the sharded code path forced on (pipe.shard_force), so that every collective of
     the long-clip mode — the per-slot async all_gather_into_tensor of UnitExchange on RCCL's stream, the all_gather of the
     sharded per-frame stages — actually runs on RCCL."""
@@ -523,7 +523,7 @@ def _rccl_world1_worker(port, q, F):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
         assert dist.get_backend() == "nccl"
-        out = _small_clip(dev, shard=True, F=F, force=True)
+        out = _small_clip(dev, shard=True, F=F, force=True, plan=plan)
         t = torch.ones(4, device=dev)
         dist.all_reduce(t)  # the reduction bench.py takes its max-over-ranks time with
         torch.cuda.synchronize()
@@ -534,7 +534,8 @@ def _rccl_world1_worker(port, q, F):
         dist.destroy_process_group()
 
 
-def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0, force=False, graphs=False):
+def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, delay_main_cycles=0, force=False, graphs=False,
+                plan="cross_step", steps=2):
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
@@ -552,12 +553,13 @@ def _small_clip(dev, shard=False, invariant=False, window_streams=None, F=26, de
     pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
     pipe.shard_windows, pipe.batch_invariant = shard, invariant
     pipe.shard_force = force
+    pipe.shard_plan = plan
     pipe.use_graphs = graphs
     if window_streams is not None:
         pipe.window_streams = window_streams
     if delay_main_cycles:  # the main stream falls far behind the host: whatever a side stream needs from it must be ordered by events
         torch.cuda._sleep(int(delay_main_cycles))
-    vid, latents = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, 3.5, return_latents=True)
+    vid, latents = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), steps, 3.5, return_latents=True)
     return torch.cat([latents.flatten(), vid.flatten()])
 
 
@@ -593,14 +595,16 @@ def test_hipgraph_replay_of_the_forward_matches_the_eager_run(dev):
 @pytest.mark.parametrize("world,F", [(2, 26), (2, 24), (2, 50), pytest.param(4, 26, marks=pytest.mark.skipif(
     not os.environ.get("MIMO_TEST_WORLD4"), reason="four processes time-slicing one GPU take ~4 min; set MIMO_TEST_WORLD4=1 "
     "(passed on the MI355X box of round 2: profiles/r2_sharded_world4_one_gpu.txt)"))])
-def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F):
+@pytest.mark.parametrize("plan", ["cross_step", "step_sync"])
+def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F, plan):
     """one clip whose work items and per-frame stages are dealt over `world` ranks (all on this GPU,
     collectives over gloo with host staging — RCCL refuses two ranks on one device) must reproduce the single-process
     result EXACTLY (fixed canonical summation order, no atomics, split-K off on both sides).  The plan (pipeline.plan_items)
     decides what a rank runs: F = 26 (two wrapped windows) on two ranks = one whole b = 2 window each; F = 24 (one window) =
     its cond half on rank 0 and its uncond half on rank 1, as b = 1 forwards; F = 50 (three windows) = a whole window per
     rank + the third window's two halves, one per rank (whole windows and single halves mixed on one rank, two exchange
-    slots); four ranks at F = 26 = one half each."""
+    slots); four ranks at F = 26 = one half each.  plan = "cross_step" (round 6, the default): the same clips under the slot
+    schedule of plan_cross_step — F = 50 on two ranks: slots {w0, w2} whole, then w1 as its two halves, per step."""
     import torch.multiprocessing as mp
     import os
     from mimo_amd.pipeline import plan_items
@@ -613,7 +617,8 @@ def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F):
     q = ctx.Queue()
     port = 29500 + os.getpid() % 400 + 11 + world
     port += F
-    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, world, port, q, F)) for r in range(world)]
+    port += 50 if plan == "step_sync" else 0
+    procs = [ctx.Process(target=_sharded_clip_worker, args=(r, world, port, q, F, plan)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = {r: torch.from_numpy(v) for r, v in (q.get(timeout=900) for _ in procs)}
@@ -621,11 +626,13 @@ def test_sharded_long_clip_equals_single_gpu_bit_for_bit(dev, world, F):
         p_.join(timeout=120)
     assert torch.isfinite(single).all()
     assert all(torch.equal(res[r], single) for r in range(world))
-    report(f"sharded long clip ({world} ranks, F = {F}, plan item sizes {kinds}, 2 steps, fp16): latents and video bit-identical to the single-process run")
+    report(f"sharded long clip ({world} ranks, F = {F}, {plan} plan" + (f", item sizes {kinds}" if plan == "step_sync" else "") +
+           ", 2 steps, fp16): latents and video bit-identical to the single-process run")
 
 
+@pytest.mark.parametrize("plan", ["cross_step", "step_sync"])
 @pytest.mark.parametrize("F", [26, 50])
-def test_rccl_branch_world1_equals_plain_run_bit_for_bit(dev, F):
+def test_rccl_branch_world1_equals_plain_run_bit_for_bit(dev, F, plan):
     """The `nccl` (RCCL) branch of the long-clip mode on the one GPU of this box: a process group of ONE rank with the
     sharded path forced on runs the unit plan (whole windows as b = 2 items on alternating HIP streams), UnitExchange's
     async all_gather_into_tensor per slot on RCCL's stream, and the sharded per-frame stages' all_gather — and reproduces the
@@ -634,15 +641,15 @@ def test_rccl_branch_world1_equals_plain_run_bit_for_bit(dev, F):
     single = _small_clip(dev, invariant=True, F=F).cpu()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 400 + 431 + F
-    p_ = ctx.Process(target=_rccl_world1_worker, args=(port, q, F))
+    port = 29500 + os.getpid() % 400 + 431 + F + (7 if plan == "step_sync" else 0)
+    p_ = ctx.Process(target=_rccl_world1_worker, args=(port, q, F, plan))
     p_.start()
     status, val, ar = q.get(timeout=900)
     p_.join(timeout=120)
     assert status == "ok", val
     assert ar == 4.0
     assert torch.equal(torch.from_numpy(val), single)
-    report(f"RCCL branch (backend nccl, world 1, forced sharding, F = {F}): latents and video bit-identical to the plain run")
+    report(f"RCCL branch (backend nccl, world 1, forced sharding, {plan} plan, F = {F}): latents and video bit-identical to the plain run")
 
 
 def _edit_template(n=44, H=120, W=160, seed=0):
