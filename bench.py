@@ -457,6 +457,9 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--edit", action="store_true", help="add the `edit` sub-record: BASELINE configs[2], the whole run_edit.py path timed")
+    ap.add_argument("--vae-encode", default="split", choices=["split", "half"],
+                    help="precision policy of the VAE encoder (mimo_amd.vae): split = hi + lo operand pairs, 3x the encoder's MFMA work, "
+                         "meets the 1e-3 bar in isolation (default, the product's default) | half = plain 16-bit operands")
     ap.add_argument("--shard-windows", action="store_true")
     ap.add_argument("--shard-plan", default="cross_step", choices=["cross_step", "step_sync"],
                     help="schedule of the sharded long clip: slots of (window, step) forwards without a per-step barrier (default) | "
@@ -511,6 +514,7 @@ def main():
     pipe.use_graphs = a.graphs and not pipe.shard_windows
     if a.window_streams is not None:
         pipe.window_streams = a.window_streams
+    pipe.vae.encode_precision = a.vae_encode
     if a.tile_vae:
         pipe.vae.enable_tiling(a.tile_vae)
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
@@ -574,7 +578,9 @@ def main():
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),
                        "kernel_launches_per_clip": clip_launches,
                        "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs),
-                       "vae_tile_rows": a.tile_vae or None, **shard_plan(a, frames, world)},
+                       "vae_tile_rows": a.tile_vae or None, "vae_encode_precision": a.vae_encode,
+                       "encoder_dedup": "runs of bit-identical input frames are encoded once (the synthetic background is one white frame, as in run_animate.py)",
+                       **shard_plan(a, frames, world)},
             # dominant kernel = gemm_kernel (implicit-GEMM convs + linears, ~2/3 of the forward): algorithmic FLOPs of all
             # its launches in one denoising forward / the sum of their HIP-event durations
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel", "achieved": gk["flops"] / (gk["ms"] * 1e-3) / 1e12,

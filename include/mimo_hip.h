@@ -37,6 +37,7 @@ extern "C" {
 
 #define MIMO_F16 0
 #define MIMO_BF16 1
+#define MIMO_F32 2   /* accepted by mimo_u8_to_tokens only (an fp32 image for the VAE's split-operand policy) */
 
 /* epilogue flags shared by mimo_gemm / mimo_conv2d */
 #define MIMO_EPI_SILU 1u      /* v = silu(v) after the bias terms, before the residual */
@@ -449,7 +450,7 @@ int mimo_tokens_to_image(const void* in, int in_is_f32, int dtype, int64_t ld, i
 int mimo_resample_pass_u8(const void* src, int src_is_f32, int64_t src_stride_n, int64_t src_stride_y,
                           int64_t src_stride_x, int64_t src_stride_c, void* dst, int n, int Hd, int Wd, int C,
                           const int* bounds, const int* coeffs, int ksize, int horizontal, void* stream);
-/* uint8 [npix, C] -> half16 tokens [npix, Cpad] = x / 255 (fp32), optionally 2 x - 1; channels >= C zero
+/* uint8 [npix, C] -> half16 (dtype MIMO_F32: fp32) tokens [npix, Cpad] = x / 255 (fp32), optionally 2 x - 1; channels >= C zero
  *   (VaeImageProcessor.preprocess as configured at pipeline_...roiclip.py:73-80). */
 int mimo_u8_to_tokens(int dtype, const void* src, int64_t npix, int C, int Cpad, int two_x_minus_1, void* dst,
                       void* stream);

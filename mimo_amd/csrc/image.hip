@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256) void u8_to_tokens_kernel(const uint8_t* src, i
   }
 }
 
+// the same values kept in fp32 (the VAE encoder's split-operand policy takes an fp32 image: no rounding of the input at all)
+__global__ __launch_bounds__(256) void u8_to_tokens_f32_kernel(const uint8_t* src, int64_t npix, int C, int cpad, int two_x_minus_1,
+                                                               float* dst) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    for (int c = 0; c < cpad; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        v = (float)src[i * C + c] / 255.0f;
+        if (two_x_minus_1) v = 2.0f * v - 1.0f;
+      }
+      dst[i * cpad + c] = v;
+    }
+  }
+}
+
 // uint8 HWC -> fp32 planar [n, C, H, W] = (x * rescale - mean[c]) / std[c]
 __global__ __launch_bounds__(256) void u8_to_planar_kernel(const uint8_t* src, int n, int64_t HW, int C, float rescale,
                                                            const float* mean, const float* stdv, float* dst) {
@@ -180,6 +195,8 @@ extern "C" int mimo_u8_to_tokens(int dtype, const void* src, int64_t npix, int C
     hipLaunchKernelGGL(u8_to_tokens_kernel<MIMO_F16>, dim3(grid_for(npix)), dim3(256), 0, st, (const uint8_t*)src, npix, C, Cpad, two_x_minus_1, (uint16_t*)dst);
   else if (dtype == MIMO_BF16)
     hipLaunchKernelGGL(u8_to_tokens_kernel<MIMO_BF16>, dim3(grid_for(npix)), dim3(256), 0, st, (const uint8_t*)src, npix, C, Cpad, two_x_minus_1, (uint16_t*)dst);
+  else if (dtype == MIMO_F32)
+    hipLaunchKernelGGL(u8_to_tokens_f32_kernel, dim3(grid_for(npix)), dim3(256), 0, st, (const uint8_t*)src, npix, C, Cpad, two_x_minus_1, (float*)dst);
   else
     return MIMO_EDTYPE;
   MIMO_LAUNCH_CHECK();

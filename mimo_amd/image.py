@@ -149,7 +149,7 @@ def pil_to_u8(images, device):
 
 
 class ImageTokens(torch.Tensor):
-    """Marker type of pre-tokenised images (half tokens [n, h, w, 8] from vae_preprocess): the pipeline recognises them by
+    """Marker type of pre-tokenised images (half — or fp32 — tokens [n, h, w, 8] from vae_preprocess): the pipeline recognises them by
     TYPE, not by shape and dtype — a half NCHW batch of width 8 is a legal image input and must not be mistaken for tokens."""
 
     @staticmethod
@@ -158,7 +158,8 @@ class ImageTokens(torch.Tensor):
 
 
 def vae_preprocess(images, height, width, normalize, dtype, device, scale_factor=8):
-    """list of PIL images -> half tokens [n, h, w, 8] (channels 3..7 zero), as VaeImageProcessor.preprocess does it."""
+    """list of PIL images -> half tokens [n, h, w, 8] (channels 3..7 zero), as VaeImageProcessor.preprocess does it.
+    dtype torch.float32: the same values unrounded (the input of the VAE encoder's split-operand policy)."""
     if len(images) == 0:
         raise ValueError("vae_preprocess needs at least one image (got an empty list)")
     w, h = width - width % scale_factor, height - height % scale_factor
@@ -170,7 +171,7 @@ def vae_preprocess(images, height, width, normalize, dtype, device, scale_factor
         if (size[0], size[1]) != (w, h):
             u8 = resize_u8(u8, (h, w), "lanczos")
         tok = torch.empty((len(idx), h, w, 8), device=device, dtype=dtype)
-        L.call("mimo_u8_to_tokens", ops.dt_code(dtype), u8.data_ptr(), len(idx) * h * w, 3, 8, int(bool(normalize)),
+        L.call("mimo_u8_to_tokens", L.F32 if dtype == torch.float32 else ops.dt_code(dtype), u8.data_ptr(), len(idx) * h * w, 3, 8, int(bool(normalize)),
                tok.data_ptr(), ops._stream())
         for j, i in enumerate(idx):
             out[i] = tok[j:j + 1]

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # are read from the environment); the default is the shipped library.
 LIB_PATH = os.environ.get("MIMO_HIP_LIB") or os.path.join(_HERE, "libmimo_hip.so")
 
-F16, BF16 = 0, 1
+F16, BF16, F32 = 0, 1, 2
 EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, EPI_NO_SPLITK = 1, 2, 4, 8, 16
 
 c_vp, c_i, c_i64, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint

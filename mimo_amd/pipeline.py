@@ -549,8 +549,10 @@ class Pose2VideoPipeline:
         dt = self.vae.compute_dtype
         from .image import ImageTokens
         tokens_in = isinstance(images, ImageTokens)
-        if tokens_in and images.dtype != dt:
-            raise ValueError(f"pre-tokenised images are {images.dtype}, the VAE computes in {dt}")
+        split = getattr(self.vae, "encode_precision", "half") == "split"
+        if tokens_in and images.dtype != dt and not (split and images.dtype == torch.float32):
+            raise ValueError(f"pre-tokenised images are {images.dtype}, the VAE computes in {dt}"
+                             + (" (fp32 tokens are the split policy's input)" if images.dtype == torch.float32 else ""))
         n = images.shape[0]
         plain = images.as_subclass(torch.Tensor) if tokens_in else images
         index = None
@@ -565,7 +567,6 @@ class Pose2VideoPipeline:
                         run_of.append(k)
                     index = torch.tensor(run_of, device=plain.device)
                     plain = plain[torch.tensor([i for i, s_ in enumerate(starts) if s_], device=plain.device)]
-        split = getattr(self.vae, "encode_precision", "half") == "split"
         hw = plain.shape[1:3] if tokens_in else plain.shape[-2:]
         nb = min(self.vae_batch, self.vae.max_images(*hw, split=split) if split else self.vae.max_images(*hw))
         outs = []
@@ -573,7 +574,8 @@ class Pose2VideoPipeline:
             chunk = plain[i:i + nb]
             if split:
                 from .vae import nchw_to_tokens32
-                # (pre-tokenised half input carries no low part: the image was rounded when it was tokenised)
+                # (pre-tokenised HALF input carries no low part: the image was rounded when it was tokenised; __call__ asks
+                # image.vae_preprocess for fp32 tokens under this policy)
                 x32 = chunk.float().contiguous() if tokens_in else nchw_to_tokens32(chunk)
                 outs.append(self.vae.encode_tokens_split(x32))
             else:
@@ -1031,7 +1033,7 @@ class Pose2VideoPipeline:
             latents = torch.randn(shape, generator=generator, device=dev, dtype=clip_embeds.dtype)
         # VaeImageProcessor.preprocess (:424-457) on the device: the host only decodes the PIL images to raw bytes;
         # LANCZOS resize, /255, 2x-1 and the token layout are kernels (image.vae_preprocess)
-        vdt = self.vae.compute_dtype
+        vdt = torch.float32 if getattr(self.vae, "encode_precision", "half") == "split" else self.vae.compute_dtype
         ref_t = IM.vae_preprocess([ref_image], height, width, True, vdt, dev)
         bk_t = IM.vae_preprocess(list(vid_bk_images), height, width, True, vdt, dev)
         pose_t = IM.vae_preprocess(list(pose_images), height, width, False, self.pose_guider.compute_dtype, dev)
