@@ -204,9 +204,13 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
     line = "config-1 (BASELINE configs[0]: 256x256, 8 f, 4 steps, full-size models) latents rel_l2 per step: " + " ".join("%.2e" % e for e in errs)
     _report(line)
     assert errs[0] < 1e-3  # one forward
-    north_star(_report, "BASELINE configs[0] final latents after four 250-step DDIM jumps (fp16)", {"step 3": errs[-1]}, 1.5e-3,
-               "the fp32 oracle under the same fp16-operand policy gives 7.8e-4 (profiles/r3_error_budget_config1.txt); four "
-               "250-step jumps chain the per-forward 7.5e-4 without the averaging of a 20-step schedule (configs[1]: 7.0e-4)")
+    north_star(_report, "BASELINE configs[0] final latents after four 250-step DDIM jumps (fp16)", {"step 3": errs[-1]}, 1.35e-3,
+               "at the floor of the 16-bit-operand policy ON THIS FIXTURE'S INPUTS: the fp32 oracle with the product's rounding points "
+               "measures 2.10e-4 / 4.98e-4 / 8.05e-4 / 1.21e-3 per step (product: 2.04e-4 / 4.73e-4 / 7.62e-4 / 1.13e-3), of which the fp16 "
+               "WEIGHTS alone are 8.7e-4, 3x3-conv operands 5.3e-4, LayerNorm / GroupNorm outputs 3.8e-4, proj_out inputs 3.5e-4, shortcut "
+               "inputs 2.8e-4 (profiles/r6_error_budget_config1_golden_inputs.txt; rss 1.23e-3).  The 7.8e-4 quoted in rounds 3-5 was the "
+               "same simulation on random LATENTS (r3_error_budget_config1.txt), not on this fixture's VAE-encoded white background; four "
+               "250-step jumps chain the per-forward error without the averaging of a 20-step schedule (configs[1]: 7.0e-4)")
 
 
 @pytest.mark.gpu
@@ -240,9 +244,8 @@ def test_hip_config784_pipeline_vs_reference_golden(full_models):
     print(line)
     _report(line)
     assert errs[0] < 1e-3
-    north_star(_report, "784x784, 8 f, 4 steps (fp16)", {"latents step 3": errs[-1], "VAE-encoded reference latents": e_ref},
-               {"latents step 3": 1.5e-3, "VAE-encoded reference latents": 2e-3},
-               "VAE encoder: fp16 weight rounding alone is 1.27e-3 (profiles/r4_error_budget_vae.txt)")
+    assert errs[-1] < 1e-3       # measured 8.98e-4 (rounds 5-6)
+    assert e_ref < 1e-4          # the encoder's split-operand policy: measured 5.2e-5 (policy 'half', rounds 1-5: 1.15e-3)
 
 
 @pytest.mark.gpu

@@ -220,7 +220,7 @@ def test_vae_encode_decode(dev, dtype, H, W):
     # half policy, measured fp16 (round 5): encode 1.47e-3 / 1.55e-3, decode 2.14e-3 / 2.01e-3; bf16 scales with its mantissa.
     # The decoder's DEFAULT is "half" (full-size sd-vae-ft-mse decode measures 4.2e-4 at 784x784, tests/test_golden.py);
     # on these half-width random-weight models it misses the bar, which is reported as such.
-    lim = {torch.float16: (1.9e-3, 2.6e-3), torch.bfloat16: (1.6e-2, 2.1e-2)}[dtype]
+    lim = {torch.float16: (1.85e-3, 2.5e-3), torch.bfloat16: (1.55e-2, 2.0e-2)}[dtype]  # <= 1.2 x the measured figures
     assert err["encode", "half"] < lim[0], err
     north_star(report, f"half-width VAE alone {H}x{W} {dtype}, DECODE under its default policy 'half' (not a denoised-latents figure; "
                f"policy 'split' measures {err['decode', 'split']:.2e})", {"decode": err["decode", "half"]}, {"decode": lim[1]},
@@ -391,9 +391,9 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
     report(f"pipeline F26 2 steps {dtype}: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W)
-    # CFG at guidance 3.5: regression guard 2e-3 (see test_pipeline_edge_cases_vs_oracle for the bound and the bisect; measured
-    # 1.44e-3 / 9.4e-4 in round 4); bf16 carries 8x the rounding (measured 1.11e-2 / 7.4e-3) and cannot meet 1e-3 at all
-    guard = {torch.float16: 2.0e-3, torch.bfloat16: 1.6e-2}[dtype]
+    # CFG at guidance 3.5 (see test_pipeline_edge_cases_vs_oracle for the bound and the bisect).  Regression guards = 1.2 x the
+    # round-6 measurements (fp16 1.40e-3 / 9.5e-4; bf16 1.13e-2 / 7.5e-3: 8x the rounding, cannot meet 1e-3 at all)
+    guard = {torch.float16: {"latents": 1.68e-3, "video": 1.14e-3}, torch.bfloat16: {"latents": 1.36e-2, "video": 9.0e-3}}[dtype]
     north_star(report, f"half-width models, F = 26, 2 steps, guidance 3.5, {dtype}", {"latents": e_lat, "video": e_vid}, guard,
                "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt)" if dtype == torch.float16
                else "bf16 operands: 8 mantissa bits (stated limit, DESIGN.md section 4)")
@@ -436,8 +436,10 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     if guidance == 1.0:
         assert e_lat < 1.0e-3 and e_vid < 1.0e-3
     else:
+        # regression guards = 1.2 x the round-6 measurements (F = 1: 1.40e-3 / 9.4e-4; F = 3: 1.21e-3 / 7.5e-4)
+        guard = {1: {"latents": 1.68e-3, "video": 1.13e-3}, 3: {"latents": 1.45e-3, "video": 9.1e-4}}[F]
         north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw}x{hw} fp16", {"latents": e_lat, "video": e_vid},
-                   2.0e-3, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
+                   guard, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
 
 
 def test_pipeline_rejects_what_the_reference_cannot_run(dev):
@@ -747,7 +749,7 @@ def test_run_edit_end_to_end_vs_oracle_chain(dev):
            f"video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, max |d|={int(d.max())}, "
            f"{100 * float((d > 1).mean()):.3f} % of values off by more than 1")
     assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
-    north_star(report, "run_edit MIMO.run end to end, half-width models (decoded video, round 4: 7.5e-4)", {"video": e_vid}, 2e-3, CFG_CAUSE)
+    north_star(report, "run_edit MIMO.run end to end, half-width models (decoded video, rounds 4-6: 7.5e-4)", {"video": e_vid}, 9.1e-4, CFG_CAUSE)
 
 
 def test_run_animate_end_to_end_vs_oracle_chain(dev):
@@ -804,7 +806,7 @@ def test_run_animate_end_to_end_vs_oracle_chain(dev):
     report(f"run_animate MIMO.run end to end ({F} frames, fp16): video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, "
            f"max |d|={int(d.max())}, {100 * float((d > 1).mean()):.3f} % of values off by more than 1")
     assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
-    north_star(report, "run_animate MIMO.run end to end, half-width models (decoded video)", {"video": e_vid}, 2e-3, CFG_CAUSE)
+    north_star(report, "run_animate MIMO.run end to end, half-width models (decoded video; round 6: 1.13e-3)", {"video": e_vid}, 1.36e-3, CFG_CAUSE)
 
 
 def test_pipeline_call_surface_pil_inputs(dev):
@@ -856,5 +858,5 @@ def test_pipeline_call_surface_pil_inputs(dev):
                             torch.stack([to_t(p) for p in poses]), lat, 2, 3.5)
     e = rel_l2(out, vid_o)
     report(f"pipeline __call__ (PIL inputs, HIP CLIP, per-frame backgrounds) fp16: video rel_l2={e:.2e}")
-    north_star(report, "Pose2VideoPipeline.__call__ with PIL inputs, half-width models (decoded video, round 4: 1.01e-3)", {"video": e}, 2.0e-3,
+    north_star(report, "Pose2VideoPipeline.__call__ with PIL inputs, half-width models (decoded video, round 6: 1.02e-3)", {"video": e}, 1.22e-3,
                CFG_CAUSE)
