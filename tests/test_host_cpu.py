@@ -871,7 +871,7 @@ def test_run_animate_frame_preparation():
 def test_video_io_round_trips_and_frame_selection(tmp_path):
     """mimo_amd.video_io: the codec-free stand-ins of `load_video_fixed_fps` / `imageio.mimsave` — a directory of frames, lossless
     animated WebP and APNG round-trip bit for bit and keep their frame rate; the selection is keep_frame_indices (pinned against the
-    reference's loader below); an mp4 path fails loudly without imageio."""
+    reference's loader below); a missing mp4 path fails loudly."""
     import numpy as np
     from mimo_amd import video_io as V
     from mimo_amd.run_edit import keep_frame_indices
@@ -926,6 +926,90 @@ def test_video_io_avi_mjpeg_and_raw(tmp_path):
     (tmp_path / "foreign.avi").write_bytes(bytes(bad))
     with pytest.raises(RuntimeError):
         V.read_frames(str(tmp_path / "foreign.avi"))
+
+
+def test_video_io_mp4_motion_jpeg(tmp_path):
+    """mimo_amd.video_io MP4 (round 6, SURVEY 8f rank 3: the container the reference's templates and results use): the muxed file
+    is a well-formed ISO base media file (nested box sizes, ftyp first, moov in front of mdat, one video track, `mp4v` + esds with
+    object type 0x6C, sample table consistent with the mdat payload, every sample a JPEG), frames come back within JPEG error at
+    the written frame rate (integer and 29.97), `load_video_fixed_fps` selects the reference's frames from it; a QuickTime-style
+    file built by hand (mdat first, `jpeg` entry, two chunks described by stsc runs, co64 offsets) reads too; H.264 raises."""
+    import io
+    import struct
+    import numpy as np
+    from PIL import Image
+    from mimo_amd import video_io as V
+    from mimo_amd.run_edit import keep_frame_indices
+    yy, xx = np.mgrid[0:46, 0:74]
+    frames = [np.stack([(xx * 3 + 9 * i) % 256, (yy * 5 + 3 * i) % 256, ((xx + yy) * 2 + i) % 256], -1).astype(np.uint8) for i in range(9)]
+    for fps in (25, 29.97):
+        out = V.save_video(frames, str(tmp_path / f"clip{int(fps)}.mp4"), fps=fps, codec="mjpeg!")
+        back, rate = V.read_frames(out)
+        assert abs(rate - fps) < 1e-6 and len(back) == 9 and back[0].size == (74, 46)
+        assert max(float(np.abs(np.asarray(b).astype(int) - f.astype(int)).mean()) for b, f in zip(back, frames)) < 4.0
+        sel = V.load_video_fixed_fps(out, target_fps=10)
+        idx = keep_frame_indices(9, rate, 10)
+        assert len(sel) == len(idx) and all(np.array_equal(np.asarray(a), np.asarray(back[i])) for a, i in zip(sel, idx))
+        raw = open(out, "rb").read()
+        boxes = V._mp4_boxes(memoryview(raw), 0, len(raw), [])
+        top = [(b[0][-1], b[1], b[2]) for b in boxes if len(b[0]) == 1]
+        assert [k for k, _, _ in top] == [b"ftyp", b"moov", b"mdat"] and top[-1][2] == len(raw)
+        assert raw[8:12] == b"isom"
+        at = {b[0]: (b[1], b[2]) for b in boxes}
+        stbl = (b"moov", b"trak", b"mdia", b"minf", b"stbl")
+        for need in (b"stsd", b"stts", b"stsc", b"stsz", b"stco"):
+            assert stbl + (need,) in at, need
+        assert sum(1 for b in boxes if b[0][-1] == b"trak") == 1
+        lo, hi = at[stbl + (b"stsd",)]
+        assert raw[lo + 12:lo + 16] == b"mp4v" and V._esds_object_type(raw[lo + 8:hi]) == 0x6C
+        assert struct.unpack(">HH", raw[lo + 8 + 32:lo + 8 + 36]) == (74, 46)
+        lo, _ = at[stbl + (b"stsz",)]
+        n = struct.unpack(">I", raw[lo + 8:lo + 12])[0]
+        sizes = struct.unpack(f">{n}I", raw[lo + 12:lo + 12 + 4 * n])
+        lo, _ = at[stbl + (b"stco",)]
+        assert struct.unpack(">I", raw[lo + 4:lo + 8])[0] == 1
+        off = struct.unpack(">I", raw[lo + 8:lo + 12])[0]
+        mdat_lo, mdat_hi = top[-1][1], top[-1][2]
+        assert n == 9 and off == mdat_lo and off + sum(sizes) == mdat_hi
+        for sz in sizes:                                     # every sample is a complete JPEG image
+            assert raw[off:off + 2] == b"\xff\xd8" and raw[off + sz - 2:off + sz] == b"\xff\xd9"
+            off += sz
+        lo, _ = at[(b"moov", b"trak", b"mdia", b"mdhd")]
+        ts, dur = struct.unpack(">II", raw[lo + 12:lo + 20])
+        assert abs(ts * 9 / dur - fps) < 1e-6
+    # a QuickTime-flavoured layout written by hand: mdat FIRST, 'jpeg' sample entry, 3 samples in two chunks (2 + 1), co64
+    jp = []
+    for f in frames[:3]:
+        b = io.BytesIO()
+        Image.fromarray(f).save(b, format="JPEG", quality=90)
+        jp.append(b.getvalue())
+    mdat = V._box(b"mdat", jp[0] + jp[1] + b"PAD!" + jp[2])
+    ftyp = V._box(b"ftyp", b"qt  " + struct.pack(">I", 0) + b"qt  ")
+    c0 = len(ftyp) + 8
+    c1 = c0 + len(jp[0]) + len(jp[1]) + 4
+    entry = b"\0" * 6 + struct.pack(">H", 1) + b"\0" * 16 + struct.pack(">HHIIIH", 74, 46, 0x480000, 0x480000, 0, 1) + b"\0" * 32 + struct.pack(">Hh", 24, -1)
+    stbl = V._box(b"stbl", V._full(b"stsd", 0, 0, struct.pack(">I", 1) + V._box(b"jpeg", entry)) +
+                  V._full(b"stts", 0, 0, struct.pack(">IIIII", 2, 2, 100, 1, 200)) +
+                  V._full(b"stsc", 0, 0, struct.pack(">I", 2) + struct.pack(">III", 1, 2, 1) + struct.pack(">III", 2, 1, 1)) +
+                  V._full(b"stsz", 0, 0, struct.pack(">II", 0, 3) + struct.pack(">3I", *(len(j) for j in jp))) +
+                  V._full(b"co64", 0, 0, struct.pack(">IQQ", 2, c0, c1)))
+    mdia = V._box(b"mdia", V._full(b"mdhd", 0, 0, struct.pack(">IIIIHH", 0, 0, 3000, 400, 0, 0)) +
+                  V._full(b"hdlr", 0, 0, struct.pack(">I4sIII", 0, b"vide", 0, 0, 0) + b"v\0") + V._box(b"minf", stbl))
+    sound = V._box(b"trak", V._box(b"mdia", V._full(b"hdlr", 0, 0, struct.pack(">I4sIII", 0, b"soun", 0, 0, 0) + b"s\0")))
+    (tmp_path / "qt.mov").write_bytes(ftyp + mdat + V._box(b"moov", sound + V._box(b"trak", mdia)))
+    back, rate = V.read_frames(str(tmp_path / "qt.mov"))
+    assert len(back) == 3 and abs(rate - 3000 * 3 / 400) < 1e-9
+    assert all(np.array_equal(np.asarray(b), np.asarray(Image.open(io.BytesIO(j)).convert("RGB"))) for b, j in zip(back, jp))
+    # a foreign codec names itself
+    bad = bytearray(open(str(tmp_path / "clip25.mp4"), "rb").read())
+    k = bad.index(b"mp4v")
+    bad[k:k + 4] = b"avc1"
+    (tmp_path / "h264.mp4").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError, match="avc1"):
+        V.read_frames(str(tmp_path / "h264.mp4"))
+    with pytest.raises(ValueError):
+        (tmp_path / "junk.mp4").write_bytes(b"this is not a media file at all")
+        V.read_frames(str(tmp_path / "junk.mp4"))
 
 
 def test_run_edit_frame_selection_known_answers():
