@@ -7,8 +7,10 @@
   Pose2VideoPipeline.__call__                                                           run_animate.py:208-219
   frames back as uint8 ((image * 255).astype(uint8): truncation, as the reference)      run_animate.py:221-227
 
-Not here, as in mimo_amd.run_edit: mp4 decode / encode and the TensorFlow matting graph `process_seg` — the driving video is
-handed over as decoded frames, the matting result as an optional mask.
+Not here, as in mimo_amd.run_edit: the TensorFlow matting graph `process_seg` (the matting result is an optional mask).  The
+driving video is decoded frames, or — `MIMO.run_paths`, the reference's `run(ref_img_path, template_path)` + `imageio.mimsave`
+(run_animate.py:153-160, 231-249) — the template directory's `sdc.mp4` read through mimo_amd.video_io (Motion-JPEG mp4 / mov /
+avi, frame directories; H.264 needs imageio + ffmpeg).
 """
 import numpy as np
 import torch
@@ -73,3 +75,16 @@ class MIMO:
             return res, 30
         host = res.cpu().numpy()
         return [host[i] for i in range(host.shape[0])], 30
+
+    def run_paths(self, ref_img_path, template_path, outpath, ref_mask=None, **save_kw):
+        """run_animate.py:153-160 + 231-249 (`main`): reference image file + template directory (its `sdc.mp4`, or .mov / .avi / a
+        frame directory of that name) in, video file out at 30 fps."""
+        import os
+        from . import video_io as V
+        src = next((os.path.join(template_path, "sdc" + e) for e in (".mp4", ".mov", ".m4v", ".avi", ".webp", "")
+                    if os.path.exists(os.path.join(template_path, "sdc" + e))), None)
+        if src is None:
+            raise FileNotFoundError(f"{template_path}: no sdc.mp4 (or .mov / .avi / frame directory)")
+        frames, fps = V.read_frames(src)
+        res, target_fps = self.run(Image.open(ref_img_path).convert("RGB"), frames, fps=fps, ref_mask=ref_mask)
+        return V.save_video(res, outpath, target_fps, **save_kw)

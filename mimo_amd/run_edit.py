@@ -6,9 +6,12 @@
   Pose2VideoPipeline.__call__                                                           run_edit.py:241-251
   per-frame compositing (resize, un-pad, paste, edge mask, occluder, clip cross-fade)   run_edit.py:253-304 (mimo_amd.edit, on the device)
 
-What is NOT here, and why: mp4 decode / encode (`imageio`: no codec library in this image) and the TensorFlow matting
-graph `process_seg` (asset + runtime absent).  A template is therefore handed over as already decoded frames
-(`Template`), the matting result as an optional mask; everything between those two boundaries is this module.
+What is NOT here, and why: the TensorFlow matting graph `process_seg` (asset + runtime absent): the matting result is handed over
+as an optional mask.  A template is either already decoded frames (`Template(...)`) or the reference's template DIRECTORY
+(`Template.from_dir`: vid.mp4 / sdc.mp4 / bk.mp4 / occ.mp4 + config.json, run_edit.py:132-151) read through mimo_amd.video_io —
+mp4 / mov / avi carrying Motion-JPEG, frame directories and animated images are decoded here, H.264 needs imageio + ffmpeg (absent
+in this image; such a file raises, naming its codec).  `MIMO.run_paths` is the reference's `run(ref_img_path, template_path)` +
+`imageio.mimsave` (run_edit.py:314-330) over the same containers.
 `keep_frame_indices` and `time_crop_range` are the codec-free parts of `load_video_fixed_fps` / the time crop: which
 decoded frames the reference keeps.
 """
@@ -46,6 +49,41 @@ class Template:
         self.fps = fps
         self.target_fps = target_fps if target_fps is not None else fps
         self.time_crop = time_crop or {"start_idx": 0, "end_idx": 10 ** 9}
+
+    @classmethod
+    def from_dir(cls, template_path):
+        """run_edit.py:132-151 `load_template` + the four `load_video_fixed_fps` readers' decode half (:171-190): vid / sdc / bk /
+        occ as `<name>.mp4` (or .mov / .avi / .webp / a directory `<name>/` of stills, first that exists) and config.json
+        (`fps`, `time_crop`).  The frame SELECTION stays in MIMO.select_frames (the reference resamples every video from its
+        own rounded native rate to the template's fps)."""
+        import json
+        import os
+        from . import video_io as V
+        with open(os.path.join(template_path, "config.json")) as fh:
+            cfg = json.load(fh)
+
+        def find(name):
+            for ext in (".mp4", ".mov", ".m4v", ".avi", ".webp", ".apng", ".gif", ""):
+                p = os.path.join(template_path, name + ext)
+                if os.path.exists(p):
+                    return p
+            return None
+
+        def load(name, required=True):
+            p = find(name)
+            if p is None:
+                if required:
+                    raise FileNotFoundError(f"{template_path}: no {name}.mp4 (or .mov / .avi / frame directory)")
+                return None, None
+            return V.read_frames(p)
+
+        vid, fps = load("vid")
+        pose, fps_p = load("sdc")
+        bk, _ = load("bk", required=False)
+        occ, _ = load("occ", required=False)
+        if round(fps_p) != round(fps):
+            raise ValueError(f"{template_path}: vid and sdc have different frame rates ({fps} / {fps_p}); Template holds one `fps`")
+        return cls(vid, pose, bk=bk, occ=occ, fps=fps, target_fps=cfg["fps"], time_crop=cfg.get("time_crop"))
 
 
 class MIMO:
@@ -107,3 +145,10 @@ class MIMO:
             return res, tpl.target_fps
         host = res.cpu().numpy()
         return [host[i] for i in range(host.shape[0])], tpl.target_fps
+
+    def run_paths(self, ref_img_path, template_path, outpath, ref_mask=None, **save_kw):
+        """run_edit.py:314-330 (`main`): reference image file + template directory in, video file out (`imageio.mimsave(outpath,
+        res, fps=target_fps)` there; mimo_amd.video_io.save_video here: .mp4 = imageio + ffmpeg when present, else Motion-JPEG mp4)."""
+        from . import video_io as V
+        res, fps = self.run(Image.open(ref_img_path).convert("RGB"), Template.from_dir(template_path), ref_mask=ref_mask)
+        return V.save_video(res, outpath, fps, **save_kw)

@@ -1012,6 +1012,37 @@ def test_video_io_mp4_motion_jpeg(tmp_path):
         V.read_frames(str(tmp_path / "junk.mp4"))
 
 
+def test_template_from_dir_reads_the_reference_layout(tmp_path):
+    """run_edit.Template.from_dir: the reference's template directory (vid.mp4 / sdc.mp4 / bk.mp4 / occ.mp4 + config.json,
+    run_edit.py:132-151) with Motion-JPEG mp4 files -> decoded frames, native rate, target fps and time crop; occ is optional;
+    MIMO.select_frames then keeps what load_video_fixed_fps keeps (25 fps -> 10 fps) inside the time crop."""
+    import json
+    import numpy as np
+    from mimo_amd import video_io as V
+    from mimo_amd.run_edit import MIMO, Template, keep_frame_indices, time_crop_range
+    yy, xx = np.mgrid[0:32, 0:48]
+    mk = lambda k: [np.stack([(xx * 3 + 9 * i + k) % 256, (yy * 5 + k) % 256, ((xx + yy) + i) % 256], -1).astype(np.uint8) for i in range(20)]
+    d = tmp_path / "tpl"
+    d.mkdir()
+    for k, name in enumerate(("vid", "sdc", "bk")):
+        V.save_video(mk(40 * k), str(d / f"{name}.mp4"), fps=25, codec="mjpeg!")
+    (d / "config.json").write_text(json.dumps({"fps": 10, "time_crop": {"start_idx": 3, "end_idx": 18}, "frame_crop": {}, "layer_recover": True}))
+    tpl = Template.from_dir(str(d))
+    assert (len(tpl.vid), len(tpl.pose), len(tpl.bk), tpl.occ) == (20, 20, 20, None)
+    assert abs(tpl.fps - 25.0) < 1e-9 and tpl.target_fps == 10 and tpl.time_crop == {"start_idx": 3, "end_idx": 18}
+    m = MIMO.__new__(MIMO)
+    m.max_frame_num = 150
+    vid, pose, bk, occ = m.select_frames(tpl)
+    idx = keep_frame_indices(20, 25.0, 10)
+    s_, e_ = time_crop_range(10, 3, 18, len(idx))
+    assert occ is None and len(vid) == len(pose) == len(bk) == e_ - s_
+    assert all(np.array_equal(np.asarray(a), np.asarray(tpl.pose[i])) for a, i in zip(pose, idx[s_:e_]))
+    with pytest.raises(FileNotFoundError):
+        (tmp_path / "empty").mkdir()
+        (tmp_path / "empty" / "config.json").write_text(json.dumps({"fps": 10}))
+        Template.from_dir(str(tmp_path / "empty"))
+
+
 def test_run_edit_frame_selection_known_answers():
     """run_edit.keep_frame_indices / time_crop_range: the codec-free arithmetic of load_video_fixed_fps
     (tools/util.py:462-479) and of the time crop (run_edit.py:194-198)."""
