@@ -147,7 +147,7 @@ def pmc_traffic(family):
     """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     over tools/profile_forward.py (same models, same shapes; PMC passes cannot run inside the timed region).
     None when no summary has been committed for this build (tools/pmc_traffic.py writes it)."""
-    for name in ("r5_pmc_forward_traffic.json", "r4_pmc_forward_traffic.json", "r3_pmc_forward_traffic.json", "r2_pmc_forward_traffic.json", "r1_pmc_forward_traffic.json"):  # newest first
+    for name in ("r6_pmc_forward_traffic.json", "r5_pmc_forward_traffic.json", "r4_pmc_forward_traffic.json", "r3_pmc_forward_traffic.json", "r2_pmc_forward_traffic.json", "r1_pmc_forward_traffic.json"):  # newest first
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             d = json.load(open(path))[family]

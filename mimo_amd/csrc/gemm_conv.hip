@@ -1713,6 +1713,8 @@ extern "C" int mimo_tune_trace(unsigned long long* dst, int n) {
     hipLaunchKernelGGL((gemm_kernel<DT, NR, MODE, WM_, WN_, NS_, MT_>), dim3((unsigned)(nwg_)), dim3(thr_), 0, st, g);      \
   } while (0)
 
+constexpr int GEMM_BM64_DEFAULT = 1;   // (tune build: MIMO_GEMM_BM64)
+
 template <int DT, int MODE, int NR>
 int launch_nr(GemmArgs& g, hipStream_t st) {
 #ifdef MIMO_TUNE
@@ -1838,6 +1840,18 @@ int launch_nr(GemmArgs& g, hipStream_t st) {
     g.tiles_n = tn_s;
     const int64_t nwg = ((g.M + 127) / 128) * tn_s;
     if (nwg <= 0 || nwg > 0x7fffffff) return MIMO_EINVAL;
+    // Small-M dense launches (the 8 x 8 level: M = 3072, N = 1280 -> 192 blocks of 128 x 160, one per CU on three quarters of
+    // the chip, each a serial chain of K / 64 round trips): 64-row tiles double the blocks (two per CU: 57 KB of LDS each), i.e.
+    // the bytes in flight per CU, which is what a latency-bound launch is short of.  A function of (M, N) only; the K order of
+    // every output element is unchanged, so the result is bit-identical to the 128-row tile's.
+    if constexpr (MODE == 0) {
+      if (tune_env("MIMO_GEMM_BM64", GEMM_BM64_DEFAULT) && nwg <= cus && !geglu) {
+        const int64_t nwg64 = ((g.M + 63) / 64) * tn_s;
+        MIMO_LAUNCH_GK(2, 2, 2, 2, nwg64, 256);
+        MIMO_LAUNCH_CHECK();
+        return MIMO_OK;
+      }
+    }
     MIMO_LAUNCH_GK(2, 2, 2, 4, nwg, 256);
   }
   (void)geglu;
