@@ -73,8 +73,19 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : 2)) void attn_kernel(const Attn
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, li = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // Block -> (query block, head, batch).  Workgroups are handed to the 8 XCDs round-robin in linear dispatch order (x fastest),
+  // so with the plain blockIdx mapping the query blocks of ONE (batch, head) — which all stream the same K / V — land on 8
+  // different L2s and each of them fetches that K / V again (measured: 1.22 GB fetched per level-1 launch for 0.19 GB of
+  // operands, profiles/r6_pmc_traffic_by_kernel_before_grouping.txt).  xcd_remap gives an XCD a contiguous run of logical ids:
+  // consecutive query blocks of a head share one L2.
+  const unsigned nqb_ = gridDim.x, nh_ = gridDim.y;
+  const unsigned Lr_ = xcd_remap((blockIdx.z * nh_ + blockIdx.y) * nqb_ + blockIdx.x, nqb_ * nh_ * gridDim.z);
+  const int head = (int)((Lr_ / nqb_) % nh_);
+  int b = (int)(Lr_ / (nqb_ * nh_));
+  // (a contiguous run per XCD would give the first XCDs the short, self-only rows of a CFG batch and the last ones the rows
+  // that also attend the bank: alternate long and short batch rows, as attn40_kernel does)
+  if (a.k2 && a.Nk2 > 0 && 2 * a.seg2_first_batch == a.B) b = (b & 1) ? (b >> 1) : a.seg2_first_batch + (b >> 1);
+  const int q0 = (int)(Lr_ % nqb_) * 128 + wave * 32;
 
   // zero the LDS once: pad columns / rows are never written again
   for (int i = tid; i < NBUF * KSZ / 2; i += 256) reinterpret_cast<uint32_t*>(Ks)[i] = 0u;
@@ -1144,8 +1155,10 @@ __global__ __launch_bounds__(256, 1) void attn512_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h2 = lane >> 5, li = lane & 31, g = lane >> 4, i16 = lane & 15;
-  const int b = blockIdx.y;
-  const int q0 = blockIdx.x * 32;
+  // (query blocks of one image on one XCD: see attn_kernel)
+  const unsigned Lr_ = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int b = (int)(Lr_ / gridDim.x);
+  const int q0 = (int)(Lr_ % gridDim.x) * 32;
   const int dw0 = wave * DW;
   unsigned char* const vpatch = smem + wave * VB;
   f32x4* const sred = reinterpret_cast<f32x4*>(smem + 4 * VB);

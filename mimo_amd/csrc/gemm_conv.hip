@@ -54,7 +54,7 @@ struct GemmArgs {
   float out_scale;
   unsigned flags;
   int tiles_n;
-  unsigned ntiles;     // persistent kernels: number of output tiles
+  unsigned ntiles;     // persistent kernels: number of output tiles; gemm8_kernel: row panels per tile-order group (0 | 1: row-major)
   void* ws;            // split-K workspace (fp32 partial tiles), may be null
   size_t ws_bytes;
   // conv geometry
@@ -1335,6 +1335,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_dense_persis
   MIMO_TRACE_REAL(g, tr, 0xff);
 }
 
+constexpr int G8_GM = 4;   // gemm8_kernel: row panels per tile-order group (tune build: MIMO_G8_GM; 1 = plain row-major order)
+
 // Dense GEMM, 256 x 256 x 64 tile, EIGHT phases per pair of K-tiles with the two wave groups half a phase apart
 // (cdna_hip_programming.md, "The 256^2 8-phase template"): 8 waves = 2 (M) x 4 (N), each 128 x 64 of the tile (128 accumulator
 // registers).  A K-tile is four phases, one 64 x 32 quadrant of the wave's output each (16 MFMAs):
@@ -1359,9 +1361,27 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GemmArgs g) {
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = (int)(wave_u >> 2), wc = (int)(wave_u & 3u);
   const int lg = lane >> 4, li = lane & 15;
+  // Tile order.  The 32 tiles an XCD runs at a time walk K in step, so its L2 serves every operand panel they SHARE once: with
+  // the plain row-major order (tile_n fastest) a window is ONE A panel x 32 W tiles — 33 panel streams for 32 tiles, and a wide
+  // GEMM (N = 10240: 40 column tiles) re-fetches the whole weight for every A panel (measured: 1.33 GB fetched per launch for
+  // 58 MB of operands, profiles/r6_pmc_traffic_by_kernel_before_grouping.txt).  Groups of G8_GM row panels walked row-fastest
+  // make the window G8_GM x (32 / G8_GM): 12 streams for 32 tiles.
   const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t M0 = (int64_t)(L / (unsigned)g.tiles_n) * BM;
-  const int N0 = (int)(L % (unsigned)g.tiles_n) * BN;
+  unsigned tile_m, tile_n;
+  {
+    const unsigned tn = (unsigned)g.tiles_n, tm = gridDim.x / tn;          // (grid = tiles_m x tiles_n exactly)
+    const unsigned gm = g.ntiles;
+    if (gm <= 1u || tn <= 8u) {
+      tile_m = L / tn; tile_n = L % tn;
+    } else {
+      const unsigned per = gm * tn, grp = L / per, first = grp * gm;
+      const unsigned rows = tm - first < gm ? tm - first : gm;              // the last group may be short
+      const unsigned r = L - grp * per;
+      tile_m = first + r % rows; tile_n = r / rows;
+    }
+  }
+  const int64_t M0 = (int64_t)tile_m * BM;
+  const int N0 = (int)tile_n * BN;
   const int nkt = g.nkt;  // even (host)
   [[maybe_unused]] u32x4 rsq[EPI == 2 ? ROW_STAT_LOADS : 1], csq;
   if constexpr (EPI == 2) row_stats_issue(g, M0, N0, BM, BN, tid, rsq, csq);   // (all out of range without a_row_stats)
@@ -1895,6 +1915,7 @@ int launch(const GemmArgs& g0, hipStream_t st) {
     const bool n_fits = tn8 * 256 - g.N <= g.N / 12;
     if (p8 && !g.colstats && !g.ln_out && (g.K % 128) == 0 && n_fits && nt8 >= 128 && nt8 <= 0x7fffffff && g.M < 0x7fffffff) {
       g.tiles_n = (int)tn8;
+      g.ntiles = (unsigned)tune_env("MIMO_G8_GM", G8_GM);
       if (g.row_half || g.a_row_stats) hipLaunchKernelGGL((gemm8_kernel<DT, 2>), dim3((unsigned)nt8), dim3(512), 0, st, g);
       else hipLaunchKernelGGL((gemm8_kernel<DT>), dim3((unsigned)nt8), dim3(512), 0, st, g);
       MIMO_LAUNCH_CHECK();
