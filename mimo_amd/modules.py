@@ -405,9 +405,10 @@ class SpatialTransformerBlock(HipModule):
             ff2_b=_f32(self.ff.net[2].bias),
             n1w=_f32(self.norm1.weight), n1b=_f32(self.norm1.bias),
             n3w=_f32(self.norm3.weight), n3b=_f32(self.norm3.bias),
-            # C >= 640: norm1 folded into the QKV projection, norm3 into the GEGLU projection (ops.LN_FOLD)
+            # C >= 640: norm1 folded into the QKV projection, norm3 into the GEGLU projection (ops.LN_FOLD).  Write mode (the
+            # reference UNet) banks the NORMALISED tensor, so its norm1 is never folded: no folded QKV copy is packed for it
             qkv_f=pack_ln_fold(self.qkv_weight(), self.norm1.weight, self.norm1.bias, None, dt)
-            if self.dim >= ops.LN_FOLD_MIN_C else None,
+            if (self.dim >= ops.LN_FOLD_MIN_C and self.mode != "write") else None,
             ff1_f=_fold_geglu(self.ff.net[0].proj, self.norm3, dt) if self.dim >= ops.LN_FOLD_MIN_C else None)
 
     def qkv_weight(self):
@@ -429,7 +430,8 @@ class SpatialTransformerBlock(HipModule):
         """norm1 as the `ln=` argument of the GEMM that produces this block's input (fused into its epilogue at C = 320,
         folded into the QKV projection at C >= 640 — except in write mode, which banks the normalised tensor itself)."""
         p = self.packed(dtype)
-        return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps, fold=self.mode != "write")
+        # (fold only with a folded QKV copy at hand: a block packed in write mode and switched to another mode later runs unfolded)
+        return dict(gamma=p["n1w"], beta=p["n1b"], eps=self.norm1.eps, fold=self.mode != "write" and p["qkv_f"] is not None)
 
     def run(self, ctx, t, n_img, N, out_f32=False, n1=None, proj=None, x=None, qkv=None):
         """t: fp32 tokens [n_img*N, C]; n1 = norm1(t) as half if the producer already computed it; qkv = the fused Q/K/V
@@ -622,6 +624,9 @@ class MotionModule(HipModule):
         cache = self.__dict__.setdefault("_pe_bias_cache", {})
         key = (i, b, F, p[f"pew{i}"].data_ptr())
         if key not in cache:
+            if len(cache) >= 64:  # (b, F) pairs of a few clip shapes at most; entries of re-packed weights would pile up otherwise
+                cache.clear()
+                _PACK_EPOCH[0] += 1   # a captured hipGraph may hold a dropped entry by address: force its re-capture
             cache[key] = p[f"pew{i}"][:F].repeat(b, 1).contiguous()
         return cache[key]
 
