@@ -460,6 +460,9 @@ def main():
     ap.add_argument("--vae-encode", default="split", choices=["split", "half"],
                     help="precision policy of the VAE encoder (mimo_amd.vae): split = hi + lo operand pairs, 3x the encoder's MFMA work, "
                          "meets the 1e-3 bar in isolation (default, the product's default) | half = plain 16-bit operands")
+    ap.add_argument("--unet-precision", default="half", choices=["half", "split"],
+                    help="precision policy of both UNets: half = 16-bit MFMA operands + the fused kernels (default, the benchmarked "
+                         "path) | split = hi + lo operand pairs, unfused (mimo_amd.precise): the reference-grade mode, ~3x the MFMA work")
     ap.add_argument("--shard-windows", action="store_true")
     ap.add_argument("--shard-plan", default="cross_step", choices=["cross_step", "step_sync"],
                     help="schedule of the sharded long clip: slots of (window, step) forwards without a per-step barrier (default) | "
@@ -515,6 +518,7 @@ def main():
     if a.window_streams is not None:
         pipe.window_streams = a.window_streams
     pipe.vae.encode_precision = a.vae_encode
+    pipe.denoising_unet.precision = pipe.reference_unet.precision = a.unet_precision
     if a.tile_vae:
         pipe.vae.enable_tiling(a.tile_vae)
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
@@ -578,7 +582,7 @@ def main():
                        "frames_total": total_frames, "clip_executed_tflop": round(clip_flops / 1e12, 2),
                        "kernel_launches_per_clip": clip_launches,
                        "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs),
-                       "vae_tile_rows": a.tile_vae or None, "vae_encode_precision": a.vae_encode,
+                       "vae_tile_rows": a.tile_vae or None, "vae_encode_precision": a.vae_encode, "unet_precision": a.unet_precision,
                        "encoder_dedup": "runs of bit-identical input frames are encoded once (the synthetic background is one white frame, as in run_animate.py)",
                        **shard_plan(a, frames, world)},
             # dominant kernel = gemm_kernel (implicit-GEMM convs + linears, ~2/3 of the forward): algorithmic FLOPs of all

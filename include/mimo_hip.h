@@ -219,9 +219,13 @@ int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int C2, int x_
  * half16 channel blocks per token, out[tok][0..C) = out[tok][C..2C) = hi = half(y), out[tok][2C..3C) = lo = half(y - hi);
  * row stride ldo >= 3 C elements (columns beyond 3 C are left untouched: the caller zero-fills padding once).  Multiplied by a
  * weight packed [Whi | Wlo | Whi] along K by the ordinary mimo_gemm / mimo_conv2d the fp32 accumulators receive
- * hi.Whi + hi.Wlo + lo.Whi: both operands carry ~22 mantissa bits.  C % 8 == 0, ldo % 8 == 0, 16-byte aligned pointers. */
+ * hi.Whi + hi.Wlo + lo.Whi: both operands carry ~22 mantissa bits.  C % 8 == 0, ldo % 8 == 0, 16-byte aligned pointers.
+ * x may be one source of a virtual channel concat (the skip connections, src/models/unet_3d_blocks.py:697,827): c_total > 0 =
+ * channels of the concatenated tensor that `groups`, `stats`, `gamma`, `beta` describe, c_off = this source's first channel
+ * in it (c_total <= 0: x is the whole tensor). */
 int mimo_group_norm_apply_split3(const float* x, int C, int dtype, int n, int64_t HW, int groups, const float* stats,
-                                 const float* gamma, const float* beta, int silu, void* out, int64_t ldo, void* stream);
+                                 const float* gamma, const float* beta, int silu, void* out, int64_t ldo, int c_off, int c_total,
+                                 void* stream);
 /* GroupNorm folded to a per-(image, channel) affine: ab fp32 [n][2][C], ab[i][0][c] = rstd(i, g(c)) * gamma[c],
  * ab[i][1][c] = beta[c] - mean(i, g(c)) * ab[i][0][c], so that GroupNorm(x)[c] = x * a + b.  The operand of
  * mimo_conv3x3_fused (the apply pass of src/models/resnet.py:20-28,220-221,237 without a pass over the tensor). */

@@ -327,8 +327,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x1, int C1, c
 template <int DT>
 __global__ __launch_bounds__(256) void gn_apply_split3_kernel(const float* x, int C, int n, int64_t HW, int groups,
                                                               const float* stats, const float* gamma, const float* beta,
-                                                              int silu, uint16_t* out, int64_t ldo) {
-  const int cpg = C / groups;
+                                                              int silu, uint16_t* out, int64_t ldo, int c_off, int c_total) {
+  // (x may be ONE source of a virtual channel concat of c_total channels starting at channel c_off: groups, gamma and beta
+  // are those of the concatenated tensor)
+  const int cpg = c_total / groups;
   const int c8 = C / 8;
   const int64_t total = (int64_t)n * HW * c8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -342,10 +344,10 @@ __global__ __launch_bounds__(256) void gn_apply_split3_kernel(const float* x, in
     if (stats) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int grp = (c + k) / cpg;
+        const int grp = (c_off + c + k) / cpg;
         const float mean = stats[((int64_t)img * groups + grp) * 2];
         const float rstd = stats[((int64_t)img * groups + grp) * 2 + 1];
-        const float t = (v[k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        const float t = (v[k] - mean) * rstd * gamma[c_off + c + k] + beta[c_off + c + k];
         v[k] = silu ? silu_f(t) : t;
       }
     }
@@ -595,17 +597,20 @@ extern "C" int mimo_group_norm_apply(const void* x1, int C1, const void* x2, int
 }
 
 extern "C" int mimo_group_norm_apply_split3(const float* x, int C, int dtype, int n, int64_t HW, int groups, const float* stats,
-                                            const float* gamma, const float* beta, int silu, void* out, int64_t ldo, void* stream) {
+                                            const float* gamma, const float* beta, int silu, void* out, int64_t ldo, int c_off,
+                                            int c_total, void* stream) {
   if (!x || !out || n <= 0 || HW <= 0 || C <= 0 || (C & 7) || ldo < 3 * (int64_t)C || (ldo & 7)) return MIMO_EINVAL;
-  if (stats && (!gamma || !beta || groups <= 0 || C % groups)) return MIMO_EINVAL;
+  if (c_total <= 0) { c_off = 0; c_total = C; }
+  if (c_off < 0 || c_off + C > c_total) return MIMO_EINVAL;
+  if (stats && (!gamma || !beta || groups <= 0 || c_total % groups)) return MIMO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return MIMO_EINVAL;
   if (!stats) groups = 1;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = stream_grid((int64_t)n * HW * (C / 8));
   if (dtype == MIMO_F16)
-    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo);
+    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_F16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo, c_off, c_total);
   else if (dtype == MIMO_BF16)
-    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo);
+    hipLaunchKernelGGL(gn_apply_split3_kernel<MIMO_BF16>, dim3(grid), dim3(256), 0, st, x, C, n, HW, groups, stats, gamma, beta, silu, (uint16_t*)out, ldo, c_off, c_total);
   else
     return MIMO_EDTYPE;
   MIMO_LAUNCH_CHECK();

@@ -59,7 +59,7 @@ SIGNATURES = {
     "mimo_group_norm_stats_slabs": [c_vp, c_i, c_i, c_vp, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp],
     "mimo_group_norm_stats": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_f, c_vp, c_vp, c_i, c_vp],
     "mimo_group_norm_apply": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp],
-    "mimo_group_norm_apply_split3": [c_vp, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i64, c_vp],
+    "mimo_group_norm_apply_split3": [c_vp, c_i, c_i, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_i64, c_i, c_i, c_vp],
     "mimo_group_norm_affine": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
     "mimo_conv3x3_fused": [c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i, c_vp, c_i64, c_vp, ctypes.POINTER(HconvParams), c_vp, c_vp, c_vp,
                            c_vp, c_vp, c_f, c_u, c_vp],

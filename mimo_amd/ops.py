@@ -589,11 +589,13 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
                             want_norm=want_norm)
 
 
-def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype=torch.float16, ld=None):
+def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype=torch.float16, ld=None, c_off=0, c_total=0):
     """The split-operand form of an fp32 activation (mimo_group_norm_apply_split3): half [..., ld >= 3C] = [hi | hi | lo] of
     y = silu?(GroupNorm(x)) with the given statistics (fp32 [n, groups, 2]) or of x itself (stats None) — the A operand of a
     GEMM / convolution whose weight is packing.pack_conv_split3 / pack_linear_split3 ([Whi | Wlo | Whi] along K): both
-    operands then carry ~22 mantissa bits through the fp16 MFMAs.  x: fp32 [n, H, W, C] or [M, C]; ld > 3C: zero padding."""
+    operands then carry ~22 mantissa bits through the fp16 MFMAs.  x: fp32 [n, H, W, C] or [M, C]; ld > 3C: zero padding.
+    c_total > 0: x is the source that starts at channel c_off of a virtual concat of c_total channels (stats / gamma / beta are
+    the concatenated tensor's)."""
     _chk(x, "x")
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
     C = x.shape[-1]
@@ -602,9 +604,10 @@ def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype
     ld = 3 * C if ld is None else int(ld)
     out = (torch.zeros if ld > 3 * C else torch.empty)(tuple(x.shape[:-1]) + (ld,), device=x.device, dtype=dtype)
     if stats is not None:
-        assert stats.is_contiguous() and stats.shape == (n, groups, 2) and gamma.numel() == C and beta.numel() == C
+        ct = c_total if c_total > 0 else C
+        assert stats.is_contiguous() and stats.shape == (n, groups, 2) and gamma.numel() == ct and beta.numel() == ct
     L.call("mimo_group_norm_apply_split3", x.data_ptr(), C, dt_code(dtype), n, HW, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-           int(silu), out.data_ptr(), ld, _stream())
+           int(silu), out.data_ptr(), ld, int(c_off), int(c_total), _stream())
     return out
 
 

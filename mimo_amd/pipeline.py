@@ -73,6 +73,16 @@ def interpolate_latents(latents, interpolation_factor):
     return torch.stack(frames, dim=2).contiguous()
 
 
+def fill_window_tokens(latents, idx, out, C, dt):
+    """latents fp32 [1, C, F, h, w], frames idx -> token rows out[..., :C] ([len(idx), h, w, >= C]): the layout kernel for 16-bit
+    tokens; a torch layout copy for fp32 tokens (the UNets' split precision policy takes its input unrounded)."""
+    if out.dtype == torch.float32:
+        out[..., :C] = latents[0][:, idx.long()].permute(1, 2, 3, 0)
+    else:
+        ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=out)
+    return out
+
+
 class Pose2VideoPipelineOutput:
     def __init__(self, videos):
         self.videos = videos
@@ -679,8 +689,10 @@ class Pose2VideoPipeline:
         if not sharded and self.window_streams > 1:
             side = self._streams(dev)[0]
             side.wait_stream(main)
+        bdt = torch.float32 if getattr(unet, "precision", "half") == "split" else dt   # the background latents' token type
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), ops.workspace_slot(1 if side is not None else 0):
-            ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=self.reference_unet.compute_dtype)
+            ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=torch.float32 if getattr(self.reference_unet, "precision", "half") == "split"
+                                  else self.reference_unet.compute_dtype)
             ref_tok[..., :C] = ref_lat.to(ref_tok.dtype)
             rctx = Ctx(self.reference_unet.compute_dtype, 1, 1)
             rctx.stop_after = writer.last_block()
@@ -690,10 +702,10 @@ class Pose2VideoPipeline:
                 pass
 
         if sharded:  # one long clip over the ranks: the per-frame stages are sharded too
-            bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev), rank, world, self.dist_group).to(dt)
+            bk_tok = sharded_frames(self._encode_frames, bk_images.to(dev), rank, world, self.dist_group).to(bdt)
             pose_tok = sharded_frames(pose_fn, pose_images.to(dev), rank, world, self.dist_group)
         else:
-            bk_tok = self._encode_frames(bk_images.to(dev)).to(dt)             # [F,h,w,4]
+            bk_tok = self._encode_frames(bk_images.to(dev)).to(bdt)            # [F,h,w,4]
             pose_tok = pose_fn(pose_images.to(dev))                            # fp32 [F,h,w,C0]
 
         if side is not None:
@@ -704,6 +716,10 @@ class Pose2VideoPipeline:
         reader.update(writer)
         mark("vae_encode+pose_guider+reference_unet")
 
+        # (the UNets' split precision policy, mimo_amd.precise, takes fp32 tokens: nothing of its input is rounded)
+        xdt = torch.float32 if getattr(unet, "precision", "half") == "split" else dt
+        if xdt == torch.float32 and self.use_graphs:
+            raise NotImplementedError("hipGraph replay covers the default precision policy only")
         windows = get_context_scheduler(context_schedule)(0, num_inference_steps, F, context_frames, context_stride,
                                                           context_overlap)
         win_idx = [torch.tensor(c, dtype=torch.int32, device=dev) for c in windows]
@@ -714,7 +730,7 @@ class Pose2VideoPipeline:
         # the layout kernel (one launch per CFG copy) — no torch.cat / repeat inside the step loop.
         win_x = []
         for c in win_idx:
-            xw = torch.empty((rep * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+            xw = torch.empty((rep * c.numel(), h, w, 2 * C), device=dev, dtype=xdt)
             xw[..., C:] = bk_tok[c.long()].repeat(rep, 1, 1, 1)
             win_x.append(xw)
         if rep > 1:
@@ -723,7 +739,7 @@ class Pose2VideoPipeline:
         def fill_latents(wi):
             idx, Fw = win_idx[wi], win_idx[wi].numel()
             for r_ in range(rep):
-                ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=win_x[wi][r_ * Fw:(r_ + 1) * Fw])
+                fill_window_tokens(latents, idx, win_x[wi][r_ * Fw:(r_ + 1) * Fw], C, dt)
             return win_x[wi]
 
         # time-embedding projections of ALL steps and the collapsed cross-attentions of the clip: four GEMMs per clip
@@ -734,7 +750,7 @@ class Pose2VideoPipeline:
         item_x, item_pose = [], []
         for item in my_items:  # per-item UNet input / pose buffers of the sharded mode (same layout as win_x)
             c = win_idx[item[0][0]]
-            xw = torch.empty((len(item) * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+            xw = torch.empty((len(item) * c.numel(), h, w, 2 * C), device=dev, dtype=xdt)
             xw[..., C:] = bk_tok[c.long()].repeat(len(item), 1, 1, 1)
             item_x.append(xw)
             item_pose.append(pose_tok[c.long()].repeat(len(item), 1, 1, 1))
@@ -813,7 +829,7 @@ class Pose2VideoPipeline:
                     with torch.cuda.stream(streams[slot]), ops.workspace_slot(1 + slot if conc else 0):
                         x = item_x[k]
                         for r_ in range(len(item)):
-                            ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=x[r_ * Fw:(r_ + 1) * Fw])
+                            fill_window_tokens(latents, idx, x[r_ * Fw:(r_ + 1) * Fw], C, dt)
                         if len(item) == 2:  # the whole window, batched exactly as on one GPU
                             pred = unet.run_tokens(x, t, ehs, 2, Fw, item_pose[k], **tk)
                             preds = [pred[:Fw], pred[Fw:]]
@@ -904,7 +920,7 @@ class Pose2VideoPipeline:
             key = (wi, rows)
             if key not in in_x:
                 c = win_idx[wi].long()
-                xw = torch.empty((rows * c.numel(), h, w, 2 * C), device=dev, dtype=dt)
+                xw = torch.empty((rows * c.numel(), h, w, 2 * C), device=dev, dtype=bk_tok.dtype if bk_tok.dtype == torch.float32 else dt)
                 xw[..., C:] = bk_tok[c].repeat(rows, 1, 1, 1)
                 in_x[key], in_pose[key] = xw, pose_tok[c].repeat(rows, 1, 1, 1)
             return in_x[key], in_pose[key]
@@ -956,7 +972,7 @@ class Pose2VideoPipeline:
                 assert all(frame_step[f] == t for f in windows[wi]), "cross-step plan ran ahead of its dependencies"
                 x, pose = item_input(wi, len(halves))
                 for r_ in range(len(halves)):
-                    ops.ncfhw_to_tokens(latents, dt, frame_idx=idx, cpad=C, out=x[r_ * n_f:(r_ + 1) * n_f])
+                    fill_window_tokens(latents, idx, x[r_ * n_f:(r_ + 1) * n_f], C, dt)
                 if len(halves) == 2:
                     pred = unet.run_tokens(x, steps_t[t], ehs, 2, n_f, pose, temb=temb_tab[t], attn2=attn2_tab)
                     preds = [pred[:n_f], pred[n_f:]]

@@ -214,6 +214,39 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
 
 
 @pytest.mark.gpu
+def test_hip_config1_pipeline_split_policy_meets_the_bar(full_models):
+    """BASELINE configs[0] under the split precision policy (both UNets; the VAE encoder has it by default): the final latents
+    after the four 250-step jumps, 1.13e-3 under the default policy (= its floor on this fixture, see the test above), are within
+    the north star's 1e-3 of the reference's fp32 run."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    G = gold("config1_256_8f_4steps.safetensors")
+    dev = torch.device("cuda:0")
+    H = W = 256
+    F = 8
+    g = torch.Generator().manual_seed(11)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.ones(F, 3, H, W)
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    m = full_models
+    m["ref"].precision = m["den"].precision = "split"
+    try:
+        pipe = Pose2VideoPipeline(m["vae"], None, m["ref"], m["den"], m["pose"], DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+        traj = []
+        pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 4, 3.5, trajectory=traj, decode=False)
+    finally:
+        m["ref"].precision = m["den"].precision = "half"
+    errs = [rel_l2(traj[i].cpu(), G[f"latents_step{i}"]) for i in range(4)]
+    line = "config-1 (BASELINE configs[0]) under the SPLIT precision policy: latents rel_l2 per step: " + " ".join("%.2e" % e for e in errs)
+    print(line)
+    _report(line)
+    assert errs[-1] < 1e-3, errs
+
+
+@pytest.mark.gpu
 def test_hip_config784_pipeline_vs_reference_golden(full_models):
     """The scripts' DEFAULT frame size (run_animate.py:43-55: 784x784 -> 98x98 latents, odd sizes down the UNet) through the
     whole tensor path with full-size models: VAE encode of the reference image and 8 background frames, pose guider,
