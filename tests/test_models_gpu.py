@@ -506,9 +506,17 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     if guidance == 1.0:
         assert e_lat < 1.0e-3 and e_vid < 1.0e-3
     else:
+        # the same clip under the split precision policy (UNets + VAE decode): within the bar
+        p3.precision = p2.precision = "split"
+        pv.decode_precision = "split"
+        vid_s, lat_s = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, guidance, return_latents=True)
+        es_lat, es_vid = rel_l2(lat_s.cpu(), lat_o), rel_l2(vid_s.cpu(), vid_o)
+        report(f"pipeline edge F={F} guidance={guidance} {hw}x{hw} fp16 SPLIT policy: latents rel_l2={es_lat:.2e} video rel_l2={es_vid:.2e}")
+        assert es_lat < 1e-3 and es_vid < 1e-3
         # regression guards = 1.2 x the round-6 measurements (F = 1: 1.40e-3 / 9.4e-4; F = 3: 1.21e-3 / 7.5e-4)
         guard = {1: {"latents": 1.68e-3, "video": 1.13e-3}, 3: {"latents": 1.45e-3, "video": 9.1e-4}}[F]
-        north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw}x{hw} fp16", {"latents": e_lat, "video": e_vid},
+        north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw}x{hw} fp16, DEFAULT policy (split policy: "
+                   f"{es_lat:.2e})", {"latents": e_lat, "video": e_vid},
                    guard, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
 
 
@@ -876,7 +884,18 @@ def test_run_animate_end_to_end_vs_oracle_chain(dev):
     report(f"run_animate MIMO.run end to end ({F} frames, fp16): video rel_l2={e_vid:.2e}; uint8 frames mean |d|={d.mean():.3f}, "
            f"max |d|={int(d.max())}, {100 * float((d > 1).mean()):.3f} % of values off by more than 1")
     assert d.mean() < 0.5 and float((d > 1).mean()) < 5e-3 and int(d.max()) <= 8
-    north_star(report, "run_animate MIMO.run end to end, half-width models (decoded video; round 6: 1.13e-3)", {"video": e_vid}, 1.36e-3, CFG_CAUSE)
+    # the same entry under the split precision policy (UNets + both VAE directions; the CLIP encoder stays on 16-bit operands)
+    p3.precision = p2.precision = "split"
+    pv.decode_precision = "split"
+    m2 = MIMO(pipe, width=W, height=H, steps=2, cfg=3.5, seed=42, max_frame_num=8)
+    res2, _ = m2.run(ref_img, pose, fps=30, ref_mask=ref_mask)
+    e_split = rel_l2(m2.last["video"].cpu(), vid_o[0])
+    d2 = np.abs(np.stack(res2).astype(np.int32) - res_o.astype(np.int32))
+    report(f"run_animate MIMO.run end to end under the SPLIT policy: video rel_l2={e_split:.2e}; uint8 frames max |d|={int(d2.max())}, "
+           f"{100 * float((d2 > 0).mean()):.3f} % of values differ")
+    assert e_split < 1e-3
+    north_star(report, "run_animate MIMO.run end to end, half-width models, DEFAULT policy (decoded video; round 6: 1.13e-3; split policy: "
+               f"{e_split:.2e})", {"video": e_vid}, 1.36e-3, CFG_CAUSE)
 
 
 def test_pipeline_call_surface_pil_inputs(dev):
