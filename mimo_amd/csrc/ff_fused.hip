@@ -36,6 +36,10 @@
 
 #include "ff_fused.hip.h"
 
+#ifndef FF_HEAD_RING   // block head: depth of the W tile ring (2: the feed-forward modes' stage layout; 3: three 40 KB tiles, two ahead).
+#define FF_HEAD_RING 2 // Measured equal (round 6, profiles/r6_block_head_ring_depth_ab.txt: 0.294-0.300 ms either way, forward 68.4-68.6): the
+#endif                 // step's wait is not the tile's latency; 2 is shipped, 3 stays as a build variant (-DFF_HEAD_RING=3)
+
 namespace {
 
 // MODE 0: feed-forward only (half output); 1: + the block's output projection; 2: + the attention output projection and
@@ -48,6 +52,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   constexpr int NFF = HEAD ? 0 : NSTEP;                 // feed-forward positions
   constexpr int NQKV = 3 * C / 64;                      // block head: W tiles of the fused QKV projection
   constexpr int NPOS = NPRE + NFF + (TAIL ? NTAIL : 0) + (HEAD ? NQKV : 0);   // stream positions (W tiles of the W1 region) per panel
+  // W ring.  The feed-forward modes: 2 stages of [W1 tile | W2 slice] (60 KB each).  Block head with FF_HEAD_RING = 3 (build
+  // variant): no W2 slices exist, so the same 120 KB hold THREE 40 KB tiles and the stream runs TWO positions ahead — a QKV
+  // step's counted wait then asks for a tile issued two steps earlier.  It measured equal to the 2-deep ring: the ~1 300 of a
+  // step's ~3 800 cycles spent in wait + barrier (profiles/r5_block_head_phase_trace.txt) are not the tile's latency
+  constexpr int RING = HEAD ? FF_HEAD_RING : 2;
+  constexpr unsigned SLOT = (HEAD && FF_HEAD_RING == 3) ? (unsigned)W1_TILE : (unsigned)STAGE;
+  static_assert(RING * SLOT <= (unsigned)BIAS_OFF, "the ring must end below the bias image");
   __shared__ __attribute__((aligned(16))) uint4 smem[LDS_BYTES / 16];  // ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
       const unsigned j2 = ld_j == 0u ? (unsigned)NPOS - 1u : ld_j - 1u;      // position ld_t - 1 inside its panel
       // (only the feed-forward positions have a W2 slice)
       const bool live2 = NFF > 0 && ld_t >= 1u && ld_t <= total && j2 >= (unsigned)NPRE && j2 < (unsigned)(NPRE + NFF);
-      const unsigned dst1 = smem_base + (ld_t & 1u) * (unsigned)STAGE;
+      const unsigned dst1 = smem_base + (ld_t % (unsigned)RING) * SLOT;
       const unsigned dst2 = smem_base + ((ld_t + 1u) & 1u) * (unsigned)STAGE + (unsigned)W1_TILE;
       // MODE 2: the W1 region's tiles are one stream in position order; MODE 1: the projection tiles are a second tensor
       const bool tail_tile = MODE == 1 && ld_j >= (unsigned)NSTEP;
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
   constexpr unsigned BIAS_Q = BIAS_OFF / 16;   // uint4 index of the bias image (4 floats per uint4)
 
   issue_next();     // W1 tile 0 (no W2 slice yet)
+  if constexpr (RING == 3) issue_next();   // block head: the stream runs two positions ahead
   __syncthreads();  // bias image complete (the compiler drains its own loads; the DMAs are invisible to it)
 
   unsigned t = 0;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
     // wave's output columns 32 q .. 32 q + 31 of its 160 are the tile's n-tiles 2 sh, 2 sh + 1) times the operand in fa
     auto proj = [&](auto q_c) {
       constexpr int q = decltype(q_c)::value;
-      const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+      const unsigned sq = (t % (unsigned)RING) * (SLOT / 16u);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const unsigned qq = sq + ((ks & 1) ? bq1 : bq0) + (unsigned)((ks >> 1) * 512);
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         FF_TRACE(g, tr, 3);
         issue_next();
         FF_TRACE(g, tr, 4);
-        const unsigned sq = (t & 1u) * (unsigned)(STAGE / 16);
+        const unsigned sq = (t % (unsigned)RING) * (SLOT / 16u);
         f32x4 a1[2][2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -425,9 +437,19 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFArgs g) {
         ++t;
         FF_TRACE(g, tr, 6);
       };
-      qkv_step(0, ICf<20>{});
+      if constexpr (RING == 3) {
+        // NEWER with the stream two positions ahead: behind the DMAs of the tile a step reads this wave has issued — step 0: the
+        // next tile's 10 pieces + the 20 y stores (the tile itself was waited for by the last projection step's vmcnt(0));
+        // step 1: the y stores + step 0's 10 pieces and 2 stores; from step 2 on: 2 stores + 10 pieces + 2 stores
+        qkv_step(0, ICf<30>{});
+        qkv_step(1, ICf<32>{});
 #pragma unroll 1
-      for (int q = 1; q < NQKV; ++q) qkv_step(q, ICf<2>{});
+        for (int q = 2; q < NQKV; ++q) qkv_step(q, ICf<14>{});
+      } else {
+        qkv_step(0, ICf<20>{});
+#pragma unroll 1
+        for (int q = 1; q < NQKV; ++q) qkv_step(q, ICf<2>{});
+      }
       FF_TRACE(g, tr, 22);
       continue;
     }
