@@ -367,10 +367,10 @@ def _cpu_ops_patch():
     ops.ncfhw_to_tokens, ops.window_accumulate, ops.cfg_ddim_step = ncfhw_to_tokens, window_accumulate, cfg_ddim_step
 
 
-def _cross_step_case(F, steps, cfg):
+def _cross_step_case(F, steps, cfg, stride=1):
     from mimo_amd.context import uniform
     g = torch.Generator().manual_seed(F * 31 + steps)
-    windows = uniform(0, steps, F, 24, 1, 4)
+    windows = uniform(0, steps, F, 24, stride, 4)
     lat = torch.randn(1, 4, F, 3, 2, generator=g)
     bk = torch.randn(F, 3, 2, 4, generator=g)
     pose = torch.randn(F, 3, 2, 4, generator=g) * 0.1
@@ -379,7 +379,7 @@ def _cross_step_case(F, steps, cfg):
     return windows, lat, bk, pose, ehs
 
 
-def _cross_step_worker(rank, world, port, q, F, steps, cfg):
+def _cross_step_worker(rank, world, port, q, F, steps, cfg, stride=1):
     import torch.distributed as dist
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
@@ -387,7 +387,7 @@ def _cross_step_worker(rank, world, port, q, F, steps, cfg):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         _cpu_ops_patch()
-        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg)
+        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg, stride)
         pipe = Pose2VideoPipeline.__new__(Pose2VideoPipeline)
         pipe.denoising_unet, pipe.scheduler = _FakeUNet(), DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
         pipe.dist_group, pipe.stage_times = None, None
@@ -403,13 +403,14 @@ def _cross_step_worker(rank, world, port, q, F, steps, cfg):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F,steps,cfg", [(8, 192, 6, True), (4, 100, 4, True), (2, 50, 3, True), (2, 24, 3, True), (3, 72, 3, False)])
-def test_cross_step_executor_gloo_equals_sequential_loop(world, F, steps, cfg):
+@pytest.mark.parametrize("world,F,steps,cfg,stride", [(8, 192, 6, True, 1), (4, 100, 4, True, 1), (2, 50, 3, True, 1), (2, 24, 3, True, 1),
+                                                      (3, 72, 3, False, 1), (4, 100, 3, True, 2)])
+def test_cross_step_executor_gloo_equals_sequential_loop(world, F, steps, cfg, stride):
     """Pose2VideoPipeline._denoise_cross_step over gloo (world 8: the 10-window clip of BASELINE configs[3]) with a stand-in
     UNet and torch stand-ins for the elementwise kernels: every rank ends with the latents — and the per-step trajectory, and
     the callback order — of the plain per-step loop (all windows, canonical-order sum, guidance, DDIM), bit for bit.  Covers
-    the slot dependency order, the gather ring's depth, the frame-segment updates, split windows (F = 24 on 2 ranks) and the
-    no-CFG form."""
+    the slot dependency order, the gather ring's depth, the frame-segment updates, split windows (F = 24 on 2 ranks), the
+    no-CFG form, and context_stride 2 (strided windows: frames covered by up to four windows, a denser dependency graph)."""
     import torch.multiprocessing as mp
     from mimo_amd import ops
     from mimo_amd.scheduler import DDIMScheduler
@@ -417,7 +418,7 @@ def test_cross_step_executor_gloo_equals_sequential_loop(world, F, steps, cfg):
     saved = (ops.ncfhw_to_tokens, ops.window_accumulate, ops.cfg_ddim_step)
     try:
         _cpu_ops_patch()
-        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg)
+        windows, lat, bk, pose, ehs = _cross_step_case(F, steps, cfg, stride)
         sched = DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS)
         sched.set_timesteps(steps)
         net, ref_traj = _FakeUNet(), []
@@ -438,7 +439,8 @@ def test_cross_step_executor_gloo_equals_sequential_loop(world, F, steps, cfg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29200 + (os.getpid() * 3 + world * 17 + F) % 700
-    procs = [ctx.Process(target=_cross_step_worker, args=(r, world, port, q, F, steps, cfg)) for r in range(world)]
+    port += 40 * stride
+    procs = [ctx.Process(target=_cross_step_worker, args=(r, world, port, q, F, steps, cfg, stride)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=600) for _ in procs]
