@@ -234,7 +234,8 @@ def cpu_baseline(clip_flops, frames, budget_s=25.0, config2=False):
                 sample=(f"{what}, full size, fp32, {cores} threads: denoising forward on 2x{F} frames at latent {hw}x{hw} "
                         f"(BASELINE configs[{1 if config2 else 0}] size), {n} timed: {dt:.2f} s/forward, {sample_flops/1e12:.3f} TFLOP => "
                         f"{cpu_flops_per_s/1e12:.3f} TFLOP/s; extrapolated to the clip's {clip_flops/1e12:.1f} executed TFLOP "
-                        f"(model build {build_s:.0f} s untimed)"
+                        f"(model build {build_s:.0f} s untimed); a single un-warmed sample: read it as ~{frames / (clip_flops / cpu_flops_per_s):.3f} "
+                        f"+- 8 % (0.0135-0.0157 over the runs of rounds 4-6)"
                         + ("" if config2 else "; QUICK sample: at the workload's own configs[1] shape a 32-thread MI355X host sustains "
                            "0.61x this rate (profiles/r3_cpu_baseline_config2.json) — run without --cpu-baseline-quick for that number")))
 
