@@ -898,6 +898,52 @@ def test_run_animate_end_to_end_vs_oracle_chain(dev):
                f"{e_split:.2e})", {"video": e_vid}, 1.36e-3, CFG_CAUSE)
 
 
+def test_run_animate_files_in_file_out(dev, tmp_path):
+    """The reference's `main` shape (run_animate.py:231-249): a reference IMAGE FILE and a template DIRECTORY holding `sdc.mp4` in, an
+    `.mp4` out — mimo_amd.run_animate.MIMO.run_paths over mimo_amd.video_io (Motion-JPEG in ISO-BMFF both ways, the codec this
+    image has).  The frames the pipeline sees are exactly the decoded JPEG frames (same result as MIMO.run on them), and the
+    written file decodes to the generated frames within JPEG error at 30 fps."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPVisionConfig
+    from mimo_amd import video_io as V
+    from mimo_amd.clip import CLIPVisionModelWithProjection
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.run_animate import MIMO
+    from mimo_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    dtype = torch.float16
+    _, _, p3, p2 = build_pair_unets(dtype, dev, seed=91)
+    _, pv = build_pair_vae(dtype, dev, seed=92)
+    _, pg = build_pair_pose(dtype, dev, seed=93)
+    torch.manual_seed(6)
+    pclip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                                           image_size=224, patch_size=32, projection_dim=768))
+    pclip.to(dev)
+    pclip.compute_dtype = dtype
+    pipe = Pose2VideoPipeline(vae=pv, image_encoder=pclip, reference_unet=p2, denoising_unet=p3, pose_guider=pg,
+                              scheduler=DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    pose, _, _, _ = _edit_template()
+    tpl = tmp_path / "tpl"
+    tpl.mkdir()
+    V.save_video(pose[:12], str(tpl / "sdc.mp4"), fps=30, codec="mjpeg!", quality=95)
+    rs = np.random.RandomState(4)
+    ref = np.full((90, 70, 3), 255, np.uint8)
+    ref[10:80, 12:60] = rs.randint(0, 256, (70, 48, 3), dtype=np.uint8)
+    Image.fromarray(ref).save(str(tmp_path / "ref.png"))
+    out = MIMO(pipe, width=64, height=64, steps=2, cfg=3.5, seed=42, max_frame_num=8).run_paths(
+        str(tmp_path / "ref.png"), str(tpl), str(tmp_path / "result.mp4"), codec="mjpeg!", quality=98)
+    frames, fps = V.read_frames(out)
+    assert abs(fps - 30.0) < 1e-9 and len(frames) == 8 and frames[0].size == (64, 64)
+    decoded, native = V.read_frames(str(tpl / "sdc.mp4"))
+    m = MIMO(pipe, width=64, height=64, steps=2, cfg=3.5, seed=42, max_frame_num=8)
+    res, _ = m.run(Image.open(str(tmp_path / "ref.png")).convert("RGB"), decoded, fps=native)
+    d = np.abs(np.stack([np.asarray(f) for f in frames]).astype(np.int32) - np.stack(res).astype(np.int32))
+    report(f"run_animate files in / file out (sdc.mp4 -> result.mp4, Motion-JPEG): 8 frames at {fps:.0f} fps, result vs generated frames "
+           f"mean |d|={d.mean():.2f} (JPEG q98)")
+    assert d.mean() < 3.0
+
+
 def test_pipeline_call_surface_pil_inputs(dev):
     """The reference's call surface (run_animate.py:208-218 / run_edit.py): PIL reference image, lists of PIL pose and
     per-frame background images (config 3: non-constant backgrounds), CPU generator, `.videos` [1,3,F,H,W] float32 on the
