@@ -716,6 +716,12 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
     return (out, raw) if want_raw else out
 
 
+# The EDGES of a UNet take split operands (hi + lo pairs, see split3) under the default policy too: bit 0 the output head
+# (conv_norm_out + conv_out: its rounding lands on the prediction undamped), bit 1 the per-clip tables (time-embedding chain,
+# collapsed cross-attentions), bit 2 the input convolution (fed fp32 tokens: the latents are not rounded at all).  Three tiny
+# layers: +0.3 ms per forward for 15 % of its distance from the fp32 reference (one forward 7.4e-4 -> 6.3e-4, full size 768^2
+# 7.3e-4 -> 6.3e-4, configs[0] final 1.13e-3 -> 1.03e-3: tools/edge_split_probe.py, tools/config1_probe.py, round 6).  0 = off.
+EDGE_SPLIT = 7
 THIN_OUT = True  # thin-output 3x3 convolutions (conv_out of the UNet / VAE decoder) as GEMM + tap gather
 
 

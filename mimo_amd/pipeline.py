@@ -437,10 +437,10 @@ class GraphedDenoiser:
     over the C-ABI launches, which all go to the capture stream): ~430 kernel launches and the host-side dispatch
     collapse into a single replay.  Inputs live in static buffers; the bank K/V tensors are persistent per block."""
 
-    def __init__(self, unet, b, F, h, w, c0, dtype):
+    def __init__(self, unet, b, F, h, w, c0, dtype, xdtype=None):
         dev = unet.device
         self.unet, self.b, self.F = unet, b, F
-        self.x = torch.zeros((b * F, h, w, 8), device=dev, dtype=dtype)
+        self.x = torch.zeros((b * F, h, w, 8), device=dev, dtype=xdtype or dtype)   # (fp32 tokens when the input convolution takes split operands)
         self.pose = torch.zeros((b * F, h, w, c0), device=dev, dtype=torch.float32)
         # the step's rows of UNetBase.clip_tables (time-embedding projections, collapsed cross-attentions): the replay consumes
         # exactly what the eager run consumes, so the two are the same arithmetic bit for bit
@@ -689,10 +689,12 @@ class Pose2VideoPipeline:
         if not sharded and self.window_streams > 1:
             side = self._streams(dev)[0]
             side.wait_stream(main)
-        bdt = torch.float32 if getattr(unet, "precision", "half") == "split" else dt   # the background latents' token type
+        # (fp32 tokens for the UNet input when its first convolution takes split operands: the split policy, or ops.EDGE_SPLIT)
+        in32 = getattr(unet, "precision", "half") == "split" or bool(ops.EDGE_SPLIT & 4)
+        bdt = torch.float32 if in32 else dt   # the background latents' token type
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), ops.workspace_slot(1 if side is not None else 0):
-            ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=torch.float32 if getattr(self.reference_unet, "precision", "half") == "split"
-                                  else self.reference_unet.compute_dtype)
+            ref_tok = torch.zeros((1, h, w, 8), device=dev, dtype=torch.float32 if (getattr(self.reference_unet, "precision", "half") == "split"
+                                                                                   or (ops.EDGE_SPLIT & 4)) else self.reference_unet.compute_dtype)
             ref_tok[..., :C] = ref_lat.to(ref_tok.dtype)
             rctx = Ctx(self.reference_unet.compute_dtype, 1, 1)
             rctx.stop_after = writer.last_block()
@@ -717,8 +719,8 @@ class Pose2VideoPipeline:
         mark("vae_encode+pose_guider+reference_unet")
 
         # (the UNets' split precision policy, mimo_amd.precise, takes fp32 tokens: nothing of its input is rounded)
-        xdt = torch.float32 if getattr(unet, "precision", "half") == "split" else dt
-        if xdt == torch.float32 and self.use_graphs:
+        xdt = torch.float32 if in32 else dt
+        if getattr(unet, "precision", "half") == "split" and self.use_graphs:
             raise NotImplementedError("hipGraph replay covers the default precision policy only")
         windows = get_context_scheduler(context_schedule)(0, num_inference_steps, F, context_frames, context_stride,
                                                           context_overlap)
@@ -794,9 +796,9 @@ class Pose2VideoPipeline:
                 for wi, idx in enumerate(win_idx):
                     x = fill_latents(wi)                                                         # [rep*Fw,h,w,8]
                     if self.use_graphs:
-                        key = (rep, idx.numel(), h, w, dt)
+                        key = (rep, idx.numel(), h, w, dt, xdt)
                         if key not in self._graphs:
-                            self._graphs[key] = GraphedDenoiser(unet, rep, idx.numel(), h, w, pose_tok.shape[-1], dt)
+                            self._graphs[key] = GraphedDenoiser(unet, rep, idx.numel(), h, w, pose_tok.shape[-1], dt, xdt)
                         pred = self._graphs[key](x, tk["temb"], tk["attn2"], win_pose[wi])
                     else:
                         pred = unet.run_tokens(x, t, ehs, rep, idx.numel(), win_pose[wi], **tk)

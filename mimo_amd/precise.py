@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from .modules import EarlyExit, LOG2E, _f32
-from .packing import pack_conv_split3, pack_geglu, pack_linear_split3, split_hi_lo
+from .packing import pack_conv_split3, pack_conv_taps, pack_geglu, pack_linear_split3, split_hi_lo
 
 
 def _s3(x, dt, stats=None, g=None, b=None, groups=32, silu=False, c_off=0, c_total=0, ld=None):
@@ -229,7 +229,10 @@ def _unet_pack(u, dt):
              temb=pack_linear_split3(torch.cat([m.time_emb_proj.weight for m in res], 0).detach(), dt),
              a2=pack_linear_split3(torch.cat([w for w, _ in mats], 0), dt), cin_pad=cin_pad)
     if u.with_out:
-        d["co"] = pack_conv_split3(u.conv_out.weight, dt, cout_pad=(u.out_channels + 3) // 4 * 4)
+        cp = (u.out_channels + 3) // 4 * 4
+        d["co"] = pack_conv_split3(u.conv_out.weight, dt, cout_pad=cp)
+        # the thin-output form (ops.conv3x3_thin_out): per-tap weight [9 cout, Cin] -> [9 cout, 3 Cin]
+        d["co_t"] = pack_linear_split3(pack_conv_taps(u.conv_out.weight, torch.float32, cout_pad=cp), dt)
     return d
 
 
@@ -304,6 +307,15 @@ def run_tokens(u, x_tok, timestep, ehs, b, F, pose_tok=None, ctx=None, temb=None
             x = upsample(blk.upsamplers[0], ctx, x, size)
     if not u.with_out:
         return x
+    return output_head(u, x, P, p)
+
+
+def output_head(u, x, P, p):
+    """conv_norm_out + SiLU + conv_out with split operands: the thin-output form (tap GEMM + gather) where it applies."""
+    dt = u.compute_dtype
     st = ops.group_norm_stats(x, groups=u.groups, eps=u.eps, dtype=dt)
     a = _s3(x, dt, st, p["no_g"], p["no_b"], u.groups, True)
-    return ops.conv2d(a, P["co"], P["co"].shape[0], bias=p["co_b"], out_f32=True)
+    cp = P["co"].shape[0]
+    if ops.THIN_OUT and cp <= 16:
+        return ops.conv3x3_thin_out(a, P["co_t"], cp, bias=p["co_b"])
+    return ops.conv2d(a, P["co"], cp, bias=p["co_b"], out_f32=True)

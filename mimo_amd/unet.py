@@ -220,7 +220,7 @@ class UNetBase(HipModule):
         len(timesteps) * b rows instead of three M = 2 launches per forward) and the 16 collapsed cross-attentions (one
         GEMM per clip: they do not depend on the step).  Returns (temb fp32 [S, b, sum(Cout)], attn2 fp32 [b, sum(C)]);
         run_tokens(temb=..., attn2=...) then starts at conv_in.  The arithmetic per row is that of _time_and_cross."""
-        if self.precision == "split":
+        if self.precision == "split" or (ops.EDGE_SPLIT & 2):
             from . import precise
             return precise.clip_tables(self, timesteps, ehs, b)
         dt = self.compute_dtype
@@ -273,7 +273,14 @@ class UNetBase(HipModule):
         n, H, W, _ = x_tok.shape
         up = 2 ** self.num_upsamplers
         forward_upsample_size = (H % up != 0) or (W % up != 0)
-        x = ops.conv2d(x_tok, p["ci_w"], self.boc[0], bias=p["ci_b"], residual=pose_tok, out_f32=True, colstats=True)
+        if (ops.EDGE_SPLIT & 4) or x_tok.dtype == torch.float32:   # the input convolution with split operands (fp32 tokens: nothing rounded)
+            from . import precise
+            P = self.packed_split(dt, lambda d: precise._unet_pack(self, d))
+            x32 = x_tok if x_tok.dtype == torch.float32 else x_tok.float()
+            x = ops.conv2d(ops.split3(x32.contiguous(), dtype=dt, ld=P["ci"].shape[1] // 9), P["ci"], self.boc[0], bias=p["ci_b"],
+                           residual=None if pose_tok is None else pose_tok.float(), out_f32=True)
+        else:
+            x = ops.conv2d(x_tok, p["ci_w"], self.boc[0], bias=p["ci_b"], residual=pose_tok, out_f32=True, colstats=True)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk.run(ctx, x)
@@ -288,6 +295,9 @@ class UNetBase(HipModule):
             x = blk.run(ctx, x, res, size)
         if not self.with_out:
             return x
+        if ops.EDGE_SPLIT & 1:   # the output head with split operands (its rounding lands on the prediction directly)
+            from . import precise
+            return precise.output_head(self, x, self.packed_split(dt, lambda d: precise._unet_pack(self, d)), p)
         a, _ = ops.group_norm(x, p["no_g"], p["no_b"], groups=self.groups, eps=self.eps, silu=True, dtype=dt)
         if ops.THIN_OUT and p["co_w"].shape[0] <= 16:
             return ops.conv3x3_thin_out(a, p["co_wt"], p["co_w"].shape[0], bias=p["co_b"])
@@ -323,7 +333,7 @@ class UNet3DConditionModel(UNetBase):
         """sample [b,8,f,h,w], pose_cond_fea [b,320,f,h,w] -> (sample [b,4,f,h,w],) like the reference."""
         b, c, f, h, w = sample.shape
         dt = self.compute_dtype
-        if self.precision == "split":   # fp32 tokens: a layout copy, nothing is rounded
+        if self.precision == "split" or (ops.EDGE_SPLIT & 4):   # fp32 tokens: a layout copy, nothing is rounded
             x = torch.zeros((b * f, h, w, 8), device=sample.device, dtype=torch.float32)
             x[..., :c] = sample.float().permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c)
             pose = None if pose_cond_fea is None else pose_cond_fea.float().permute(0, 2, 3, 4, 1).reshape(b * f, h, w, -1).contiguous()

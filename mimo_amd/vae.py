@@ -524,8 +524,31 @@ class PoseGuider(HipModule):
         return dict(w=[pack_conv(c.weight, dt, cin_pad=8 if i == 0 else None) for i, c in enumerate(convs)],
                     b=[_f32(c.bias) for c in convs])
 
+    def run_tokens_split(self, x32):
+        """Split policy (`precision = "split"`): x32 fp32 [F,H,W,8] -> fp32 tokens [F,H/8,W/8,C]; every conv with hi + lo operands."""
+        dt = self.compute_dtype
+        convs = [self.conv_in] + list(self.blocks) + [self.conv_out]
+
+        def pack(d):
+            out = []
+            for i, c in enumerate(convs):
+                cin = 8 if i == 0 else c.in_channels
+                kp = (3 * cin + 31) // 32 * 32 if 3 * cin <= 32 else None
+                out.append(pack_conv_split3(c.weight, d, cin_pad=cin, k_pad=kp))
+            return dict(w=out)
+        P = self.packed_split(dt, pack)
+        p = self.packed(dt)
+        x = x32
+        for i, c in enumerate(convs):
+            last = i == len(convs) - 1
+            a = ops.split3(x.contiguous(), dtype=dt, ld=P["w"][i].shape[1] // 9)
+            x = ops.conv2d(a, P["w"][i], c.out_channels, stride=c.stride[0], bias=p["b"][i], silu=not last, out_f32=True)
+        return x
+
     def run_tokens(self, x_tok):
         """x_tok: half [F,H,W,8] (RGB in [0,1] + zero pad) -> fp32 tokens [F,H/8,W/8,C]."""
+        if getattr(self, "precision", "half") == "split":
+            return self.run_tokens_split(x_tok.float() if x_tok.dtype != torch.float32 else x_tok)
         p = self.packed(self.compute_dtype)
         convs = [self.conv_in] + list(self.blocks) + [self.conv_out]
         x = x_tok
