@@ -720,7 +720,10 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
 # (conv_norm_out + conv_out: its rounding lands on the prediction undamped), bit 1 the per-clip tables (time-embedding chain,
 # collapsed cross-attentions), bit 2 the input convolution (fed fp32 tokens: the latents are not rounded at all).  Three tiny
 # layers: +0.3 ms per forward for 15 % of its distance from the fp32 reference (one forward 7.4e-4 -> 6.3e-4, full size 768^2
-# 7.3e-4 -> 6.3e-4, configs[0] final 1.13e-3 -> 1.03e-3: tools/edge_split_probe.py, tools/config1_probe.py, round 6).  0 = off.
+# 7.3e-4 -> 6.3e-4, configs[0] final 1.13e-3 -> 1.03e-3: tools/edge_split_probe.py, tools/config1_probe.py, round 6).  Bit 3 (OFF):
+# the 1x1 shortcut of the LAST resnet of the denoising UNet — on the 512^2 golden forward that resnet alone carries 38 % of the
+# error variance, its shortcut product 20 % (tools/sensitivity_scan.py: 6.55e-4 -> 5.87e-4), but on configs[0] it moves the final
+# latents from 1.025e-3 to 1.020e-3 only, for +0.8 ms per forward: not in the default.  0 = everything off.
 EDGE_SPLIT = 7
 THIN_OUT = True  # thin-output 3x3 convolutions (conv_out of the UNet / VAE decoder) as GEMM + tap gather
 

@@ -54,11 +54,38 @@ def _conv_w_concat(weight, c1, dt, shortcut=None):
 
 # ---- ResnetBlock / samplers ------------------------------------------------------------------------------------------
 def resnet(blk, ctx, x, skip=None):
+    """ResnetBlock under split operands.  `blk.split_parts` (default: all of "conv1", "conv2", "sc") selects WHICH of its three
+    products take them — the 3x3 conv1, the 3x3 conv2, the fused 1x1 shortcut over the raw block input; the others run on plain
+    16-bit operands through the same launches (a probe of where a block's rounding matters: tools/sensitivity_scan.py)."""
     dt = ctx.dtype
     c1 = x.shape[-1]
     sc = blk.conv_shortcut
-    P = blk.packed_split(dt, lambda d: dict(w1=_conv_w_concat(blk.conv1.weight, c1, d),
-                                            w2=_conv_w_concat_conv2(blk, c1, d)))
+    parts = frozenset(getattr(blk, "split_parts", ("conv1", "conv2", "sc")))
+    s1, s2, ss = "conv1" in parts, "conv2" in parts, ("sc" in parts or "sc_op" in parts)
+    op_only = "sc_op" in parts   # probe: only the shortcut's OPERAND is split (its weight's low part zeroed)
+
+    def pack(d):
+        out = dict(w1=_conv_w_concat(blk.conv1.weight, c1, d) if s1 else None)
+        w2 = pack_conv_split3(blk.conv2.weight, d) if s2 else blk.conv2.weight.detach().float().permute(0, 2, 3, 1).reshape(blk.out_channels, -1).to(d)
+        if sc is not None:
+            sw = sc.weight.reshape(sc.weight.shape[0], -1)
+            if ss:
+                segs = [pack_linear_split3(sw[:, :c1], d)] + ([pack_linear_split3(sw[:, c1:], d)] if c1 < sw.shape[1] else [])
+                if op_only:
+                    for sg in segs:
+                        k = sg.shape[1] // 3
+                        sg[:, k:2 * k] = 0
+            else:
+                segs = [sw.detach().to(d)]
+            w2 = torch.cat([w2] + segs, 1)
+        out["w2"] = w2.contiguous()
+        return out
+    cache = blk.__dict__.setdefault("_pk_split_parts", {})
+    key = (parts, dt, c1)
+    if key not in cache:
+        with torch.no_grad():
+            cache[key] = pack(dt)
+    P = cache[key]
     p = blk.packed(dt)
     cout = blk.out_channels
     ct = blk.in_channels
@@ -67,17 +94,31 @@ def resnet(blk, ctx, x, skip=None):
         s, e = blk.temb_slice
         tb = ctx.temb[:, s:e]
     st1 = ops.group_norm_stats(x, groups=blk.groups, eps=blk.eps, x2=skip, dtype=dt)
-    a1 = _s3(x, dt, st1, p["g1"], p["be1"], blk.groups, True, 0, ct)
-    raw = None
-    if skip is not None:
-        a1 = torch.cat([a1, _s3(skip, dt, st1, p["g1"], p["be1"], blk.groups, True, c1, ct)], -1)
-    h = ops.conv2d(a1, P["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True)
-    st2 = ops.group_norm_stats(h, groups=blk.groups, eps=blk.eps, dtype=dt)
-    a2 = _s3(h, dt, st2, p["g2"], p["be2"], blk.groups, True)
-    if sc is not None:
-        raw = _s3(x, dt)
+    raw16 = None
+    if s1:
+        a1 = _s3(x, dt, st1, p["g1"], p["be1"], blk.groups, True, 0, ct)
         if skip is not None:
-            raw = torch.cat([raw, _s3(skip, dt)], -1)
+            a1 = torch.cat([a1, _s3(skip, dt, st1, p["g1"], p["be1"], blk.groups, True, c1, ct)], -1)
+        h = ops.conv2d(a1, P["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True)
+    else:
+        a1, raw16 = ops.group_norm_apply(x, st1, p["g1"], p["be1"], groups=blk.groups, silu=True, x2=skip, dtype=dt,
+                                         want_raw=sc is not None and not ss)
+        h = ops.conv2d(a1, p["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True)
+    st2 = ops.group_norm_stats(h, groups=blk.groups, eps=blk.eps, dtype=dt)
+    if s2:
+        a2 = _s3(h, dt, st2, p["g2"], p["be2"], blk.groups, True)
+    else:
+        a2, _ = ops.group_norm_apply(h, st2, p["g2"], p["be2"], groups=blk.groups, silu=True, dtype=dt)
+    raw = None
+    if sc is not None:
+        if ss:
+            raw = _s3(x, dt)
+            if skip is not None:
+                raw = torch.cat([raw, _s3(skip, dt)], -1)
+        else:
+            if raw16 is None:
+                _, raw16 = ops.group_norm_apply(x, None, None, None, x2=skip, dtype=dt, want_norm=False, want_raw=True)
+            raw = raw16
     return ops.conv2d(a2, P["w2"], cout, x2=raw, bias=p["b2"], residual=None if sc is not None else x, out_f32=True,
                       out_scale=1.0 / blk.output_scale_factor)
 

@@ -44,8 +44,9 @@ def main():
     pose = torch.rand(F, 3, H, W, generator=g)
     clip = torch.randn(1, 768, generator=g)
     lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
-    for name, knob, refp, posep in (("edges + tables 1|2|4", 7, "half", "half"), ("edges + tables + reference UNet split", 7, "split", "half"),
-                                    ("edges + tables + pose guider split", 7, "half", "split"), ("edges + tables + both", 7, "split", "split")):
+    for name, knob, refp, posep in (("EDGE_SPLIT = 0", 0, "half", "half"), ("EDGE_SPLIT = 7 (head, tables, conv_in)", 7, "half", "half"),
+                                    ("EDGE_SPLIT = 15 (+ last resnet's shortcut)", 15, "half", "half"),
+                                    ("EDGE_SPLIT = 15 + reference UNet split", 15, "split", "half")):
         ops.EDGE_SPLIT = knob
         m["ref"].precision = refp
         m["pose"].precision = posep
