@@ -39,6 +39,14 @@ VARIANTS = [
     ("touch+bias_init", ["-DFF4_TOUCH=1", "-DFF4_BIAS_INIT=1"]),
     ("pf1", ["-DFF4_PF=1"]),
     ("no_fence", ["-DFF4_FENCE=0"]),
+    ("mfma32", ["-DFF32_AS_FF4"]),        # csrc/ff_tail32.hip (32x32x16 MFMAs) in the place of ff_tail4.hip
+    ("mfma32_nofence", ["-DFF32_AS_FF4", "-DFF32_FENCE=0"]),
+    ("abl32_no_dma", ["-DFF32_AS_FF4", "-DFF32_ABLATE=1"]),
+    ("abl32_no_geglu", ["-DFF32_AS_FF4", "-DFF32_ABLATE=2"]),
+    ("abl32_no_mfma", ["-DFF32_AS_FF4", "-DFF32_ABLATE=4"]),
+    ("abl32_no_frag", ["-DFF32_AS_FF4", "-DFF32_ABLATE=8"]),
+    ("abl32_no_barrier", ["-DFF32_AS_FF4", "-DFF32_ABLATE=16"]),
+    ("abl32_mfma_only", ["-DFF32_AS_FF4", "-DFF32_ABLATE=27"]),
 ]
 EXTRA = {}   # name -> flags, filled from the command line: --def name=-DX=1,-DY=2
 
@@ -61,7 +69,8 @@ def build(names):
     def one(v):
         name, flags = v
         o = os.path.join(VDIR, f"ff_tail4_{name}.o")
-        r = subprocess.run(HIPCC + ["-fno-slp-vectorize", "-Wno-inline-asm"] + (flags or []) + ["-c", os.path.join(CSRC, "ff_tail4.hip"), "-o", o],
+        src = "ff_tail32.hip" if flags and "-DFF32_AS_FF4" in flags else "ff_tail4.hip"
+        r = subprocess.run(HIPCC + ["-fno-slp-vectorize", "-Wno-inline-asm"] + (flags or []) + ["-c", os.path.join(CSRC, src), "-o", o],
                            capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr[-3000:])
