@@ -469,12 +469,13 @@ def test_pipeline_two_wrapped_windows_vs_oracle(dev, dtype):
                else "bf16 operands: 8 mantissa bits (stated limit, DESIGN.md section 4)")
 
 
-@pytest.mark.parametrize("F,guidance,hw", [(1, 3.5, 64), (5, 1.0, 64), (24, 1.0, 40), (3, 3.5, 104)])
+@pytest.mark.parametrize("F,guidance,hw", [(1, 3.5, 64), (5, 1.0, 64), (24, 1.0, 40), (3, 3.5, 104), (5, 1.0, (48, 104)), (4, 1.0, (72, 40))])
 def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     """Edges of run_tensors against oracle.pipeline.run_clip: a ONE-frame clip (temporal attention over a single frame),
     guidance 1.0 (no CFG: b = 1 forwards, banks read by every row, the no-CFG quirk of cfg_ddim), a full 24-frame window
-    without CFG on a 40x40 image (5x5 latents: every level below the 32-row MFMA tile), and a 104x104 image (13x13 latents:
-    odd sizes 13 / 7 / 4 / 2 through every down- and explicit-size up-sampler) — fp16."""
+    without CFG on a 40x40 image (5x5 latents: every level below the 32-row MFMA tile), a 104x104 image (13x13 latents:
+    odd sizes 13 / 7 / 4 / 2 through every down- and explicit-size up-sampler), and two NON-SQUARE clips (height x width 48x104 =
+    6x13 latents, 72x40 = 9x5: every kernel takes H and W apart; odd and even sizes mixed per axis) — fp16."""
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import primitives as OP, synth
@@ -483,7 +484,8 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=81)
     ov, pv = build_pair_vae(dtype, dev, seed=82)
     og, pg = build_pair_pose(dtype, dev, seed=83)
-    H = W = hw
+    H, W = hw if isinstance(hw, tuple) else (hw, hw)
+    hw = f"{H}x{W}" if H != W else hw
     g = torch.Generator().manual_seed(9)
     ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
@@ -495,7 +497,8 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
     pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
     vid_p, lat_p = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, guidance, return_latents=True)
     e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
-    report(f"pipeline edge F={F} guidance={guidance} {hw}x{hw} fp16: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
+    hw = f"{hw}x{hw}" if H == W else hw
+    report(f"pipeline edge F={F} guidance={guidance} {hw} fp16: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
     assert vid_p.shape == (1, 3, F, H, W) and bool(torch.isfinite(vid_p).all())
     # Bars, not measurements: 1e-3 without CFG.  With guidance w the step combines u + w (c - u): the two branches' rounding
     # errors enter with weights (1 - w) and w while the result stays of the size of one branch (these random-weight models barely
@@ -511,11 +514,11 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
         pv.decode_precision = "split"
         vid_s, lat_s = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 2, guidance, return_latents=True)
         es_lat, es_vid = rel_l2(lat_s.cpu(), lat_o), rel_l2(vid_s.cpu(), vid_o)
-        report(f"pipeline edge F={F} guidance={guidance} {hw}x{hw} fp16 SPLIT policy: latents rel_l2={es_lat:.2e} video rel_l2={es_vid:.2e}")
+        report(f"pipeline edge F={F} guidance={guidance} {hw} fp16 SPLIT policy: latents rel_l2={es_lat:.2e} video rel_l2={es_vid:.2e}")
         assert es_lat < 1e-3 and es_vid < 1e-3
         # regression guards = 1.2 x the round-6 measurements (F = 1: 1.40e-3 / 9.4e-4; F = 3: 1.21e-3 / 7.5e-4)
         guard = {1: {"latents": 1.68e-3, "video": 1.13e-3}, 3: {"latents": 1.45e-3, "video": 9.1e-4}}[F]
-        north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw}x{hw} fp16, DEFAULT policy (split policy: "
+        north_star(report, f"half-width models edge case F = {F}, guidance {guidance}, {hw} fp16, DEFAULT policy (split policy: "
                    f"{es_lat:.2e})", {"latents": e_lat, "video": e_vid},
                    guard, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
 
