@@ -523,6 +523,41 @@ def test_pipeline_edge_cases_vs_oracle(dev, F, guidance, hw):
                    guard, "CFG amplification u + 3.5 (c - u) on random-weight models (profiles/r4_edge_case_bisect.txt); 6.8e-4 without CFG")
 
 
+@pytest.mark.parametrize("F,ctx", [(20, dict(context_frames=8, context_stride=1, context_overlap=2)),
+                                   (20, dict(context_frames=8, context_stride=2, context_overlap=4)),
+                                   (13, dict(context_frames=16, context_stride=1, context_overlap=4))])
+def test_pipeline_context_schedule_parameters_vs_oracle(dev, F, ctx):
+    """Non-default window schedules (context.py:15-42 through pipeline :505-553) against oracle.pipeline.run_clip: windows of 8
+    frames with overlap 2 (frames covered by one, two windows), context_stride 2 (a second pass of windows over every other frame:
+    strided frame indices, frames covered up to four times), and a clip SHORTER than context_frames (one window of all 13 frames) —
+    3 DDIM steps (the schedule depends on the step index), guidance 1, fp16."""
+    from mimo_amd.pipeline import Pose2VideoPipeline
+    from mimo_amd.scheduler import DDIMScheduler
+    from mimo_amd import context as CX
+    from oracle import primitives as OP, synth
+    from oracle.pipeline import run_clip
+    dtype = torch.float16
+    o3, o2, p3, p2 = build_pair_unets(dtype, dev, seed=91)
+    ov, pv = build_pair_vae(dtype, dev, seed=92)
+    og, pg = build_pair_pose(dtype, dev, seed=93)
+    H = W = 64
+    g = torch.Generator().manual_seed(19)
+    ref_img = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    bk = torch.rand(F, 3, H, W, generator=g) * 2 - 1
+    pose = torch.rand(F, 3, H, W, generator=g)
+    clip = torch.randn(1, 768, generator=g)
+    lat = torch.randn(1, 4, F, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        vid_o, lat_o = run_clip(ov, o2, o3, og, OP.DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS), clip, ref_img, bk, pose, lat, 3, 1.0, **ctx)
+    pipe = Pose2VideoPipeline(pv, None, p2, p3, pg, DDIMScheduler(**synth.NOISE_SCHEDULER_KWARGS))
+    vid_p, lat_p = pipe.run_tensors(ref_img.to(dev), bk.to(dev), pose.to(dev), clip.to(dev), lat.to(dev), 3, 1.0, return_latents=True, **ctx)
+    e_lat, e_vid = rel_l2(lat_p.cpu(), lat_o), rel_l2(vid_p.cpu(), vid_o)
+    nwin = [len(CX.uniform(i, 3, F, ctx["context_frames"], ctx["context_stride"], ctx["context_overlap"])) for i in range(3)]
+    report(f"pipeline F={F} {ctx} ({nwin} windows per step) 3 steps guidance 1.0 fp16: latents rel_l2={e_lat:.2e} video rel_l2={e_vid:.2e}")
+    assert vid_p.shape == (1, 3, F, H, W) and bool(torch.isfinite(vid_p).all())
+    assert e_lat < 1.0e-3 and e_vid < 1.0e-3
+
+
 def test_pipeline_rejects_what_the_reference_cannot_run(dev):
     """context windows longer than the motion modules' positional table (32) and context_batch_size > 1 fail loudly."""
     from mimo_amd.pipeline import Pose2VideoPipeline
