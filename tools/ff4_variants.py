@@ -39,7 +39,7 @@ VARIANTS = [
     ("touch+bias_init", ["-DFF4_TOUCH=1", "-DFF4_BIAS_INIT=1"]),
     ("pf1", ["-DFF4_PF=1"]),
     ("no_fence", ["-DFF4_FENCE=0"]),
-    ("mfma32", ["-DFF32_AS_FF4"]),        # csrc/ff_tail32.hip (32x32x16 MFMAs) in the place of ff_tail4.hip
+    ("mfma32", ["-DFF32_AS_FF4"]),        # tools/probes/ff_tail32.hip (32x32x16 MFMAs) in the place of ff_tail4.hip
     ("mfma32_nofence", ["-DFF32_AS_FF4", "-DFF32_FENCE=0"]),
     ("abl32_no_dma", ["-DFF32_AS_FF4", "-DFF32_ABLATE=1"]),
     ("abl32_no_geglu", ["-DFF32_AS_FF4", "-DFF32_ABLATE=2"]),
@@ -69,8 +69,8 @@ def build(names):
     def one(v):
         name, flags = v
         o = os.path.join(VDIR, f"ff_tail4_{name}.o")
-        src = "ff_tail32.hip" if flags and "-DFF32_AS_FF4" in flags else "ff_tail4.hip"
-        r = subprocess.run(HIPCC + ["-fno-slp-vectorize", "-Wno-inline-asm"] + (flags or []) + ["-c", os.path.join(CSRC, src), "-o", o],
+        src = os.path.join(ROOT, "tools", "probes", "ff_tail32.hip") if flags and "-DFF32_AS_FF4" in flags else os.path.join(CSRC, "ff_tail4.hip")
+        r = subprocess.run(HIPCC + ["-fno-slp-vectorize", "-Wno-inline-asm"] + (flags or []) + ["-c", src, "-o", o],
                            capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr[-3000:])

@@ -1,7 +1,7 @@
 // ff_tail32.hip — ff_tail4.hip's fused tail of a C = 320 transformer block (four waves, one per SIMD, 512 registers each, wave w
 // owns rows [32 w, 32 w + 32) of the 128-row panel and all 320 columns) on v_mfma_f32_32x32x16 instead of 16x16x32.
 //
-// NOT IN THE SHIPPED LIBRARY (mimo_amd/build.py does not list it): built, correct (1.7e-5 rel-L2 against ff4_kernel on the level-0
+// AN EXPERIMENT, NOT PRODUCT CODE (tools/ff4_variants.py builds it against csrc/ff_fused.hip; the library does not contain it): built, correct (1.7e-5 rel-L2 against ff4_kernel on the level-0
 // shape, 256 VGPR + 192 AGPR, no scratch) and measured 10 % SLOWER — 0.708 against 0.637 ms per launch, feed-forward-only entry
 // 0.581 against 0.537 (tools/ff4_variants.py `mfma32`, profiles/r6_ff_tail_mfma32_variants.txt).  The idea (round-5 / 6 verdict item
 // 3): with one wave per SIMD a 16-cycle 16x16x32 MFMA hides none of the wave's other instructions, a 32-cycle 32x32x16 MFMA hides
