@@ -465,6 +465,9 @@ def main():
                     help="precision policy of both UNets: half = 16-bit MFMA operands + the fused kernels (default, the benchmarked "
                          "path) | split = hi + lo operand pairs, unfused (mimo_amd.precise): the reference-grade mode, ~3x the MFMA work")
     ap.add_argument("--shard-windows", action="store_true")
+    ap.add_argument("--edge-split", type=int, default=None,
+                    help="mimo_amd.ops.EDGE_SPLIT for this run (default: the shipped 15; 7 = without conv2 / shortcut of the last two "
+                         "resnets on split operands: -2 ms per forward, BASELINE configs[0] then measures 1.03e-3)")
     ap.add_argument("--shard-plan", default="cross_step", choices=["cross_step", "step_sync"],
                     help="schedule of the sharded long clip: slots of (window, step) forwards without a per-step barrier (default) | "
                          "the per-step plan of rounds 2-5")
@@ -520,6 +523,8 @@ def main():
         pipe.window_streams = a.window_streams
     pipe.vae.encode_precision = a.vae_encode
     pipe.denoising_unet.precision = pipe.reference_unet.precision = a.unet_precision
+    if a.edge_split is not None:
+        ops.EDGE_SPLIT = a.edge_split
     if a.tile_vae:
         pipe.vae.enable_tiling(a.tile_vae)
     inp = synthetic_inputs(dev, frames, a.size, seed=42 + (0 if a.shard_windows else rank))
@@ -584,6 +589,7 @@ def main():
                        "kernel_launches_per_clip": clip_launches,
                        "stage_ms": {k: round(v, 1) for k, v in stage_ms.items()}, "hip_graph": bool(pipe.use_graphs),
                        "vae_tile_rows": a.tile_vae or None, "vae_encode_precision": a.vae_encode, "unet_precision": a.unet_precision,
+                       "edge_split": ops.EDGE_SPLIT,
                        "encoder_dedup": "runs of bit-identical input frames are encoded once (the synthetic background is one white frame, as in run_animate.py)",
                        **shard_plan(a, frames, world)},
             # dominant kernel = gemm_kernel (implicit-GEMM convs + linears, ~2/3 of the forward): algorithmic FLOPs of all

@@ -173,38 +173,27 @@ class ResnetBlock(HipModule):
                     g1=_f32(self.norm1.weight), be1=_f32(self.norm1.bias),
                     g2=_f32(self.norm2.weight), be2=_f32(self.norm2.bias))
 
-    def _w2_sc_split(self, dt, c1):
-        """conv2's weight with the fused 1x1 shortcut segment on split operands: [conv2 (16-bit) | per source [Shi | Slo | Shi]],
-        for a shortcut operand made by ops.split3 of the raw block input ([hi | hi | lo] per source of the virtual concat)."""
-        from .packing import pack_linear_split3
-        cache = self.__dict__.setdefault("_pk_split_parts", {})
-        key = ("w2sc", dt, c1)
-        if key not in cache:
-            with torch.no_grad():
-                sw = self.conv_shortcut.weight.detach().reshape(self.out_channels, -1)
-                segs = [pack_linear_split3(sw[:, :c1], dt)] + ([pack_linear_split3(sw[:, c1:], dt)] if c1 < sw.shape[1] else [])
-                cache[key] = torch.cat([pack_conv(self.conv2.weight, dt)] + segs, 1).contiguous()
-        return cache[key]
-
     def run(self, ctx, x, skip=None):
         """x: fp32 [n,H,W,C1]; skip: fp32 [n,H,W,C2] concatenated virtually on the channel axis.
 
         Each of the two norm -> SiLU -> conv3x3 stages is ONE launch where mimo_conv3x3_fused covers the layer (the large
         images: ops.hconv_supported, a function of the layer only): the convolution reads the fp32 tensor and applies the
         GroupNorm affine + SiLU on its LDS tile.  Elsewhere: GroupNorm-apply pass -> half tensor -> implicit-GEMM conv.
-        `self.precision = "split"` (per module, opt-in): this block on split operands (mimo_amd.precise)."""
-        if getattr(self, "precision", "half") == "split" and x.dtype == torch.float32:
-            from . import precise
-            return precise.resnet(self, ctx, x, skip)
+        `self.precision = "split"` (per module, opt-in): this block on split operands (mimo_amd.precise).
+        `self.edge_parts` (set by the owning UNet on the resnets in front of its output head, ops.EDGE_SPLIT bit 3): those of the
+        block's three products that take split operands under the DEFAULT policy — what they round reaches the prediction undamped."""
+        if x.dtype == torch.float32:
+            if getattr(self, "precision", "half") == "split":
+                from . import precise
+                return precise.resnet(self, ctx, x, skip)
+            if getattr(self, "edge_parts", None) and (ops.EDGE_SPLIT & 8):
+                from . import precise
+                return precise.resnet(self, ctx, x, skip, parts=self.edge_parts)
         p = self.packed(ctx.dtype)
         fused_sc = self.conv_shortcut is not None
         n, H, W, _ = x.shape
         cout = self.out_channels
         band = skip is None and self.time_emb_proj is None and banded(ctx, H, W)
-        # The LAST resnet of a UNet (flagged by its owner, ops.EDGE_SPLIT bit 3): its 1x1 shortcut hands the fp32 residual stream
-        # to the output through a 16-bit operand and a 16-bit weight, undamped by anything behind it — that one product takes split
-        # operands (the shortcut segment of conv2's K axis: 3 (C1 + C2) instead of C1 + C2 columns)
-        sc_split = fused_sc and getattr(self, "sc_split", False) and bool(ops.EDGE_SPLIT & 8) and x.dtype == torch.float32 and not band
         tb = None
         if self.time_emb_proj is not None:
             s, e = self.temb_slice
@@ -216,15 +205,15 @@ class ResnetBlock(HipModule):
             ab1 = ops.group_norm_affine(st1, p["g1"], p["be1"], self.in_channels, self.groups)
             # the half cast of the raw input (operand of the fused shortcut in conv2) leaves as a side output
             r = ops.conv3x3_fused(x, p["w1"], cout, x2=skip, ab=ab1, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
-                                  want_raw=fused_sc and not band and not sc_split, raw_dtype=ctx.dtype, tile_stats=True)
-            h, raw = r if (fused_sc and not band and not sc_split) else (r, None)
+                                  want_raw=fused_sc and not band, raw_dtype=ctx.dtype, tile_stats=True)
+            h, raw = r if (fused_sc and not band) else (r, None)
         elif band:
             st1 = ops.group_norm_stats(x, groups=self.groups, eps=self.eps, dtype=ctx.dtype)
             h = torch.empty((n, H, W, cout), device=x.device, dtype=torch.float32)
             gn_conv3x3_banded(ctx, x, st1, p["g1"], p["be1"], self.groups, p["w1"], cout, p["b1"], h)
         else:
             a1, raw = ops.group_norm(x, p["g1"], p["be1"], groups=self.groups, eps=self.eps, silu=True, x2=skip,
-                                     dtype=ctx.dtype, want_raw=fused_sc and not sc_split)
+                                     dtype=ctx.dtype, want_raw=fused_sc)
             # colstats=True: the conv epilogue also emits the GroupNorm column statistics of its output, so the norm
             # that consumes it (norm2 here; the next block's norm for the block output) makes no statistics pass over HBM
             h = ops.conv2d(a1, p["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True, colstats=True)
@@ -252,13 +241,7 @@ class ResnetBlock(HipModule):
                                    out_scale=1.0 / self.output_scale_factor, out=out[i:i + 1, y0:y1])
             return out
         a2, _ = ops.group_norm(h, p["g2"], p["be2"], groups=self.groups, eps=self.eps, silu=True, dtype=ctx.dtype)
-        w2 = p["w2"]
-        if sc_split:
-            raw = ops.split3(x, dtype=ctx.dtype)
-            if skip is not None:
-                raw = torch.cat([raw, ops.split3(skip, dtype=ctx.dtype)], -1)
-            w2 = self._w2_sc_split(ctx.dtype, x.shape[-1])
-        return ops.conv2d(a2, w2, cout, x2=raw, bias=p["b2"],
+        return ops.conv2d(a2, p["w2"], cout, x2=raw, bias=p["b2"],
                           residual=None if fused_sc else x, out_f32=True,
                           out_scale=1.0 / self.output_scale_factor, colstats=True)
 

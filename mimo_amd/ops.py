@@ -589,25 +589,32 @@ def group_norm(x1, gamma, beta, *, groups=32, eps=1e-5, silu=False, x2=None, dty
                             want_norm=want_norm)
 
 
-def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype=torch.float16, ld=None, c_off=0, c_total=0):
+def split3(x, stats=None, gamma=None, beta=None, *, groups=32, silu=False, dtype=torch.float16, ld=None, c_off=0, c_total=0,
+           out=None, col=0):
     """The split-operand form of an fp32 activation (mimo_group_norm_apply_split3): half [..., ld >= 3C] = [hi | hi | lo] of
     y = silu?(GroupNorm(x)) with the given statistics (fp32 [n, groups, 2]) or of x itself (stats None) — the A operand of a
     GEMM / convolution whose weight is packing.pack_conv_split3 / pack_linear_split3 ([Whi | Wlo | Whi] along K): both
     operands then carry ~22 mantissa bits through the fp16 MFMAs.  x: fp32 [n, H, W, C] or [M, C]; ld > 3C: zero padding.
     c_total > 0: x is the source that starts at channel c_off of a virtual concat of c_total channels (stats / gamma / beta are
-    the concatenated tensor's)."""
+    the concatenated tensor's).  out / col: write the 3C columns at column `col` of an existing [..., ld] tensor (the operands of
+    several sources side by side without a concat copy)."""
     _chk(x, "x")
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
     C = x.shape[-1]
     n = x.shape[0] if x.dim() == 4 else 1
     HW = x.numel() // (n * C)
-    ld = 3 * C if ld is None else int(ld)
-    out = (torch.zeros if ld > 3 * C else torch.empty)(tuple(x.shape[:-1]) + (ld,), device=x.device, dtype=dtype)
+    if out is not None:
+        ld = out.shape[-1]
+        assert out.is_contiguous() and out.dtype == dtype and out.shape[:-1] == x.shape[:-1] and col % 8 == 0 and col + 3 * C <= ld
+    else:
+        assert col == 0
+        ld = 3 * C if ld is None else int(ld)
+        out = (torch.zeros if ld > 3 * C else torch.empty)(tuple(x.shape[:-1]) + (ld,), device=x.device, dtype=dtype)
     if stats is not None:
         ct = c_total if c_total > 0 else C
         assert stats.is_contiguous() and stats.shape == (n, groups, 2) and gamma.numel() == ct and beta.numel() == ct
     L.call("mimo_group_norm_apply_split3", x.data_ptr(), C, dt_code(dtype), n, HW, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-           int(silu), out.data_ptr(), ld, int(c_off), int(c_total), _stream())
+           int(silu), out.data_ptr() + col * out.element_size(), ld, int(c_off), int(c_total), _stream())
     return out
 
 
@@ -720,11 +727,14 @@ def conv3x3_fused(x1, w, cout, *, x2=None, ab=None, bias=None, img_bias=None, im
 # (conv_norm_out + conv_out: its rounding lands on the prediction undamped), bit 1 the per-clip tables (time-embedding chain,
 # collapsed cross-attentions), bit 2 the input convolution (fed fp32 tokens: the latents are not rounded at all).  Three tiny
 # layers: +0.3 ms per forward for 15 % of its distance from the fp32 reference (one forward 7.4e-4 -> 6.3e-4, full size 768^2
-# 7.3e-4 -> 6.3e-4, configs[0] final 1.13e-3 -> 1.03e-3: tools/edge_split_probe.py, tools/config1_probe.py, round 6).  Bit 3 (OFF):
-# the 1x1 shortcut of the LAST resnet of the denoising UNet — on the 512^2 golden forward that resnet alone carries 38 % of the
-# error variance, its shortcut product 20 % (tools/sensitivity_scan.py: 6.55e-4 -> 5.87e-4), but on configs[0] it moves the final
-# latents from 1.025e-3 to 1.020e-3 only, for +0.8 ms per forward: not in the default.  0 = everything off.
-EDGE_SPLIT = 7
+# 7.3e-4 -> 6.3e-4, configs[0] final 1.13e-3 -> 1.03e-3: tools/edge_split_probe.py, tools/config1_probe.py, round 6).  Bit 3: conv2 and the
+# 1x1 shortcut of the LAST TWO resnets of the denoising UNet (ResnetBlock.edge_parts): the level-0 up block in front of the output
+# head carries 55 % (configs[0]) to 92 % (512^2 forward) of the error variance of the whole UNet, these two products of its last two
+# resnets the cheapest share of it — configs[0] final latents 1.025e-3 -> 9.31e-4 (it was the only full-size case above the 1e-3 bar),
+# one forward 6.3e-4 -> 4.9e-4, configs[1] 6.4e-4 -> 5.9e-4, for +2.0 ms per forward = 2.9 % (interleaved A/B; conv1 stays on the fused
+# launch: precise.resnet(parts=...); tools/config1_probe.py --scan [--parts], tools/sensitivity_scan.py; profiles/r6_config1_sensitivity_scan*.txt).
+# 0 = everything off.
+EDGE_SPLIT = 15
 THIN_OUT = True  # thin-output 3x3 convolutions (conv_out of the UNet / VAE decoder) as GEMM + tap gather
 
 

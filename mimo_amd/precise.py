@@ -53,14 +53,15 @@ def _conv_w_concat(weight, c1, dt, shortcut=None):
 
 
 # ---- ResnetBlock / samplers ------------------------------------------------------------------------------------------
-def resnet(blk, ctx, x, skip=None):
-    """ResnetBlock under split operands.  `blk.split_parts` (default: all of "conv1", "conv2", "sc") selects WHICH of its three
-    products take them — the 3x3 conv1, the 3x3 conv2, the fused 1x1 shortcut over the raw block input; the others run on plain
-    16-bit operands through the same launches (a probe of where a block's rounding matters: tools/sensitivity_scan.py)."""
+def resnet(blk, ctx, x, skip=None, parts=None):
+    """ResnetBlock under split operands.  `parts` / `blk.split_parts` (default: all of "conv1", "conv2", "sc") selects WHICH of its
+    three products take them — the 3x3 conv1, the 3x3 conv2, the fused 1x1 shortcut over the raw block input; the others run on
+    plain 16-bit operands through the same launches (where a block's rounding matters: tools/sensitivity_scan.py,
+    tools/config1_probe.py --scan; the default policy uses ("sc", "conv2") on the last resnets of the denoising UNet)."""
     dt = ctx.dtype
     c1 = x.shape[-1]
     sc = blk.conv_shortcut
-    parts = frozenset(getattr(blk, "split_parts", ("conv1", "conv2", "sc")))
+    parts = frozenset(parts if parts is not None else getattr(blk, "split_parts", ("conv1", "conv2", "sc")))
     s1, s2, ss = "conv1" in parts, "conv2" in parts, ("sc" in parts or "sc_op" in parts)
     op_only = "sc_op" in parts   # probe: only the shortcut's OPERAND is split (its weight's low part zeroed)
 
@@ -96,14 +97,23 @@ def resnet(blk, ctx, x, skip=None):
     st1 = ops.group_norm_stats(x, groups=blk.groups, eps=blk.eps, x2=skip, dtype=dt)
     raw16 = None
     if s1:
-        a1 = _s3(x, dt, st1, p["g1"], p["be1"], blk.groups, True, 0, ct)
-        if skip is not None:
-            a1 = torch.cat([a1, _s3(skip, dt, st1, p["g1"], p["be1"], blk.groups, True, c1, ct)], -1)
+        if skip is None:
+            a1 = _s3(x, dt, st1, p["g1"], p["be1"], blk.groups, True, 0, ct)
+        else:   # both sources of the virtual concat side by side ([hi | hi | lo] each), no concat copy
+            a1 = torch.empty(tuple(x.shape[:-1]) + (3 * ct,), device=x.device, dtype=dt)
+            ops.split3(x, st1, p["g1"], p["be1"], groups=blk.groups, silu=True, dtype=dt, c_off=0, c_total=ct, out=a1, col=0)
+            ops.split3(skip, st1, p["g1"], p["be1"], groups=blk.groups, silu=True, dtype=dt, c_off=c1, c_total=ct, out=a1, col=3 * c1)
         h = ops.conv2d(a1, P["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True)
+    elif ops.hconv_supported(x, cout, x2=skip):   # conv1 on 16-bit operands: the block's ordinary fused launch (GroupNorm + SiLU on the tile)
+        ab1 = ops.group_norm_affine(st1, p["g1"], p["be1"], blk.in_channels, blk.groups)
+        want_raw = sc is not None and not ss
+        r = ops.conv3x3_fused(x, p["w1"], cout, x2=skip, ab=ab1, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F,
+                              want_raw=want_raw, raw_dtype=dt, tile_stats=True)
+        h, raw16 = r if want_raw else (r, None)
     else:
         a1, raw16 = ops.group_norm_apply(x, st1, p["g1"], p["be1"], groups=blk.groups, silu=True, x2=skip, dtype=dt,
                                          want_raw=sc is not None and not ss)
-        h = ops.conv2d(a1, p["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True)
+        h = ops.conv2d(a1, p["w1"], cout, bias=p["b1"], img_bias=tb, imgs_per_bias_row=ctx.F, out_f32=True, colstats=True)
     st2 = ops.group_norm_stats(h, groups=blk.groups, eps=blk.eps, dtype=dt)
     if s2:
         a2 = _s3(h, dt, st2, p["g2"], p["be2"], blk.groups, True)
@@ -112,15 +122,18 @@ def resnet(blk, ctx, x, skip=None):
     raw = None
     if sc is not None:
         if ss:
-            raw = _s3(x, dt)
-            if skip is not None:
-                raw = torch.cat([raw, _s3(skip, dt)], -1)
+            if skip is None:
+                raw = _s3(x, dt)
+            else:
+                raw = torch.empty(tuple(x.shape[:-1]) + (3 * ct,), device=x.device, dtype=dt)
+                ops.split3(x, dtype=dt, out=raw, col=0)
+                ops.split3(skip, dtype=dt, out=raw, col=3 * c1)
         else:
             if raw16 is None:
                 _, raw16 = ops.group_norm_apply(x, None, None, None, x2=skip, dtype=dt, want_norm=False, want_raw=True)
             raw = raw16
     return ops.conv2d(a2, P["w2"], cout, x2=raw, bias=p["b2"], residual=None if sc is not None else x, out_f32=True,
-                      out_scale=1.0 / blk.output_scale_factor)
+                      out_scale=1.0 / blk.output_scale_factor, colstats=True)
 
 
 def _conv_w_concat_conv2(blk, c1, dt):

@@ -153,8 +153,9 @@ class UNetBase(HipModule):
         for m in self.spatial_blocks():
             m.attn2_slice = (off, off + m.dim)
             off += m.dim
-        if with_out:   # (see ResnetBlock.run: the shortcut of the last resnet in front of the output head, ops.EDGE_SPLIT bit 3)
-            self.up_blocks[-1].resnets[-1].sc_split = True
+        if with_out:   # (see ResnetBlock.run and ops.EDGE_SPLIT bit 3: the last two resnets in front of the output head)
+            for r in self.up_blocks[-1].resnets[-2:]:
+                r.edge_parts = ("sc", "conv2")
 
     # ---- plumbing ----
     @property

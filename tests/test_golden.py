@@ -203,22 +203,21 @@ def test_hip_config1_pipeline_vs_reference_golden(full_models):
     print("config-1 latents rel_l2 per step:", ["%.2e" % e for e in errs])
     line = "config-1 (BASELINE configs[0]: 256x256, 8 f, 4 steps, full-size models) latents rel_l2 per step: " + " ".join("%.2e" % e for e in errs)
     _report(line)
-    assert errs[0] < 1e-3  # one forward
-    north_star(_report, "BASELINE configs[0] final latents after four 250-step DDIM jumps (fp16)", {"step 3": errs[-1]}, 1.24e-3,
-               "at the floor of the 16-bit-operand policy ON THIS FIXTURE'S INPUTS: the fp32 oracle with the product's rounding points "
-               "measures 2.10e-4 / 4.98e-4 / 8.05e-4 / 1.21e-3 per step (product: 1.86e-4 / 4.35e-4 / 6.90e-4 / 1.03e-3 with the input "
-               "convolution, output head and per-clip tables on split operands, ops.EDGE_SPLIT; 1.13e-3 without), of which the fp16 "
-               "WEIGHTS alone are 8.7e-4, 3x3-conv operands 5.3e-4, LayerNorm / GroupNorm outputs 3.8e-4, proj_out inputs 3.5e-4, shortcut "
-               "inputs 2.8e-4 (profiles/r6_error_budget_config1_golden_inputs.txt; rss 1.23e-3).  The 7.8e-4 quoted in rounds 3-5 was the "
-               "same simulation on random LATENTS (r3_error_budget_config1.txt), not on this fixture's VAE-encoded white background; four "
-               "250-step jumps chain the per-forward error without the averaging of a 20-step schedule (configs[1]: 7.0e-4)")
+    # Every step inside the north star's 1e-3, the final latents after the four 250-step jumps included: 9.3e-4 (round 6) with the
+    # default policy's split EDGES (ops.EDGE_SPLIT = 15: input convolution, output head, per-clip tables, conv2 + shortcut of the last
+    # two resnets).  History: 1.13e-3 on plain 16-bit operands, 1.03e-3 with the first three edges — the floor of that policy on
+    # this fixture's inputs (the fp32 oracle with the product's rounding points: 1.21e-3, of which fp16 weights alone 8.7e-4,
+    # profiles/r6_error_budget_config1_golden_inputs.txt); the level-0 up block carries 55 % of the error variance
+    # (profiles/r6_config1_sensitivity_scan.txt), conv2 + shortcut of its last two resnets the cheapest share of it.
+    assert all(e < 1e-3 for e in errs), errs
+    assert errs[-1] < 9.8e-4   # regression guard: 1.05 x measured (9.31e-4)
 
 
 @pytest.mark.gpu
 def test_hip_config1_pipeline_split_policy_meets_the_bar(full_models):
     """BASELINE configs[0] under the split precision policy (both UNets; the VAE encoder has it by default): the final latents
-    after the four 250-step jumps, 1.13e-3 under the default policy (= its floor on this fixture, see the test above), are within
-    the north star's 1e-3 of the reference's fp32 run."""
+    after the four 250-step jumps (9.3e-4 under the default policy, see the test above) are five times closer to the reference's
+    fp32 run."""
     from mimo_amd.pipeline import Pose2VideoPipeline
     from mimo_amd.scheduler import DDIMScheduler
     from oracle import synth
