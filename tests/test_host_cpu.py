@@ -1243,3 +1243,28 @@ def test_pack_ln_fold_is_the_layer_norm_followed_by_the_projection():
 def test_row_stat_slots_is_a_function_of_the_width_only():
     from mimo_amd import lib as L
     assert [L.call_int("mimo_row_stat_slots", n) for n in (320, 640, 1280, 960, 100, 0)] == [4, 8, 20, 0, 0, 0]  # 960: not whole 256-wide tiles
+
+
+def test_default_precision_policy_wiring():
+    """The shipped precision policy, as host-side facts: ops.EDGE_SPLIT = 15; the denoising UNet flags exactly its last two resnets
+    (the level-0 up block in front of the output head) for split `conv2` + shortcut; the reference UNet (no output head) flags none;
+    module-level `precision` defaults to the 16-bit path; the VAE encoder defaults to split operands, the decoder to 16-bit."""
+    from mimo_amd import ops
+    from mimo_amd.modules import ResnetBlock
+    from mimo_amd.unet import UNet2DConditionModel, UNet3DConditionModel
+    from mimo_amd.vae import AutoencoderKL
+    assert ops.EDGE_SPLIT == 15
+    kw = dict(block_out_channels=(32, 64, 64, 64), attention_head_dim=4, norm_num_groups=8, cross_attention_dim=32)
+    with torch.device("meta"):
+        p3 = UNet3DConditionModel(**kw)
+        p2 = UNet2DConditionModel(**kw)
+    flagged = [n for n, m in p3.named_modules() if isinstance(m, ResnetBlock) and getattr(m, "edge_parts", None)]
+    assert flagged == ["up_blocks.3.resnets.1", "up_blocks.3.resnets.2"], flagged
+    assert all(dict(p3.named_modules())[n].edge_parts == ("sc", "conv2") for n in flagged)
+    assert not [n for n, m in p2.named_modules() if getattr(m, "edge_parts", None)]
+    assert p3.precision == "half" and p2.precision == "half"
+    assert all(getattr(m, "precision", "half") == "half" for m in p3.modules())
+    with torch.device("meta"):
+        vae = AutoencoderKL(block_out_channels=(16, 32, 32, 32), norm_num_groups=8)
+    assert vae.encode_precision == "split" and vae.decode_precision == "half"
+
