@@ -132,6 +132,16 @@ def resnet(blk, ctx, x, skip=None, parts=None):
             if raw16 is None:
                 _, raw16 = ops.group_norm_apply(x, None, None, None, x2=skip, dtype=dt, want_norm=False, want_raw=True)
             raw = raw16
+    probe = getattr(blk, "split_probe", None)   # numerical probes (tools/config1_probe.py): "w_only" = the OPERANDS' low parts zeroed
+    if probe == "w_only":                         # (= only the weights carry hi + lo), "op_only" = the weights' low parts zeroed
+        if s2:
+            a2[..., 2 * cout:] = 0
+        if ss and raw is not None:
+            if skip is None:
+                raw[..., 2 * c1:] = 0
+            else:
+                raw[..., 2 * c1:3 * c1] = 0
+                raw[..., 3 * c1 + 2 * (ct - c1):] = 0
     return ops.conv2d(a2, P["w2"], cout, x2=raw, bias=p["b2"], residual=None if sc is not None else x, out_f32=True,
                       out_scale=1.0 / blk.output_scale_factor, colstats=True)
 

@@ -48,6 +48,7 @@ def main():
     if "--scan" in sys.argv:   # which part of the denoising UNet carries configs[0]'s distance from fp32: one group at a time on split operands
         from mimo_amd.modules import MotionModule, ResnetBlock, SpatialTransformer
         import time
+        ops.EDGE_SPLIT = 7   # (the scan's baseline: without bit 3, which is what the scan is about)
         mods = {n: mod for n, mod in m["den"].named_modules() if isinstance(mod, (MotionModule, ResnetBlock, SpatialTransformer))}
 
         def run(names):
@@ -87,6 +88,14 @@ def main():
                     del mods[n].split_parts
                 print(f"{' + '.join(x[12:] for x in names):30s} {'+'.join(parts):12s} " + " ".join("%.3e" % v for v in e) +
                       f"   d(err^2) {e0[3] ** 2 - e[3] ** 2:+.3e}", flush=True)
+        for names in (["up_blocks.3.resnets.2", "up_blocks.3.resnets.1"],):   # weights-only split (operands' low parts zeroed)
+            for parts in (("sc", "conv2"), ("conv2",)):
+                for n in names:
+                    mods[n].split_parts, mods[n].split_probe = parts, "w_only"
+                e, t = run(names)
+                for n in names:
+                    del mods[n].split_parts, mods[n].split_probe
+                print(f"{' + '.join(x[12:] for x in names):30s} {'+'.join(parts):12s} WEIGHTS ONLY " + " ".join("%.3e" % v for v in e), flush=True)
         for names in (["up_blocks.3.resnets.2", "up_blocks.3.attentions.2"], ["up_blocks.3.resnets.2", "up_blocks.3.resnets.1", "up_blocks.3.attentions.2"],
                       ["up_blocks.3.resnets.2", "up_blocks.3.attentions.2", "up_blocks.3.motion_modules.2"]):
             e, t = run(names)
